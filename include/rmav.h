@@ -1,0 +1,186 @@
+/* rmav.h - C ABI of the MI355X-native batched quadrotor dynamics path (librmav.so).
+ *
+ * This is the drop-in boundary for reinmav-gym's native environments.  The reference has no FFI
+ * (it is pure Python); what a binding replaces is the body of four gym.Env classes in
+ * gym_reinmav/envs/native/ of the reference repository:
+ *
+ *   reference interface (file:line)                               entry point here
+ *   ---------------------------------------------------------------------------------------------
+ *   Quadrotor3D.__init__            quadrotor3d.py:44-74          rmav_create(RMAV_QUAD3D, ...)
+ *   Quadrotor3DSlungload.__init__   quadrotor3d_slungload.py:44-80  rmav_create(RMAV_QUAD3D_SL, ...)
+ *   Quadrotor2D.__init__            quadrotor2d.py:43-67          rmav_create(RMAV_QUAD2D, ...)
+ *   Quadrotor2DSlungload.__init__   quadrotor2d_slungload.py:43-73  rmav_create(RMAV_QUAD2D_SL, ...)
+ *   (hard-coded physics literals in each __init__)                rmav_default_params / rmav_params
+ *   .seed(seed)                     quadrotor3d.py:77-79          rmav_seed
+ *   .reset()                        quadrotor3d.py:182-185        rmav_reset
+ *   .step(action)                   quadrotor3d.py:81-124         rmav_step        (batch of N envs)
+ *                                   quadrotor3d_slungload.py:87-167
+ *                                   quadrotor2d.py:74-113
+ *                                   quadrotor2d_slungload.py:79-154
+ *   .control()                      quadrotor3d.py:126-180        rmav_control
+ *                                   quadrotor2d.py:115-138
+ *   .state / .steps_beyond_done     quadrotor3d.py:104,68         rmav_get_state / rmav_set_state,
+ *                                                                 rmav_get_sbd / rmav_set_sbd
+ *   the test loop "control -> step -> reset on done"              rmav_rollout(RMAV_ACT_CONTROLLER)
+ *                                   test/test_quadrotor3d.py:16-22
+ *   baselines VecEnv rollouts driven by gym_reinmav/run.py:89,190-211
+ *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM)
+ *   baselines Monitor episode statistics (info['episode'])        rmav_episode_totals / _buffers
+ *
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an rmav_status (0 = ok, < 0 = error) unless noted;
+ *     rmav_last_error() returns a thread-local message for the last failure; nothing throws or
+ *     aborts across this boundary.
+ *   - a handle owns the device-resident env state (fp32, struct-of-arrays) of N independent envs on
+ *     one GPU and one HIP stream; it is NOT thread-safe; distinct handles are independent.
+ *   - `mem` says where every caller-supplied pointer of that call lives: RMAV_HOST (the library
+ *     stages through device buffers and synchronises before returning) or RMAV_DEVICE (HIP device
+ *     pointers, e.g. torch tensor data_ptr(); work is enqueued on the handle's stream and the call
+ *     returns without synchronising).
+ *   - `layout`: RMAV_SOA = [dim][N] (component-major, the native device layout, coalesced) or
+ *     RMAV_AOS = [N][dim] (what gym / a policy network hands over).  Trajectory buffers of
+ *     rmav_rollout are time-major: [T][dim][N] (SOA) or [T][N][dim] (AOS).
+ *   - there is no CPU implementation behind this ABI: rmav_create fails with RMAV_ERR_NO_DEVICE
+ *     when no GPU is visible.
+ *
+ * RNG streams (Philox4x32-10, key = (seed_lo, seed_hi), counter = (env_lo, env_hi, c2, c3), where
+ * env is the GLOBAL env id = env_id_base + local index, so results do not depend on how envs are
+ * sharded over GPUs):
+ *   reset : c2 = index of this env's reset (0 for the first),  c3 = (1<<24) | j ; block j supplies
+ *           state components 4j..4j+3 as  2*u - 1,  u = (x>>8) * 2^-24          (U[-1,1), as
+ *           quadrotor3d.py:184 draws every state component)
+ *   action: c2 = low 32 bits of the handle's global step counter t,
+ *           c3 = (2<<24) | (bits 32..47 of t) << 8 ; component i = fma(act_hi-act_lo, u_i, act_lo)
+ */
+#ifndef RMAV_H
+#define RMAV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMAV_VERSION 100 /* 0.1.0 */
+
+typedef struct rmav_env_s *rmav_handle;
+
+enum rmav_kind { RMAV_QUAD2D = 0, RMAV_QUAD2D_SL = 1, RMAV_QUAD3D = 2, RMAV_QUAD3D_SL = 3 };
+
+enum rmav_status {
+    RMAV_OK = 0,
+    RMAV_ERR_INVALID = -1,   /* bad argument */
+    RMAV_ERR_NO_DEVICE = -2, /* no usable GPU */
+    RMAV_ERR_HIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
+    RMAV_ERR_ALLOC = -4      /* device / host allocation failed */
+};
+
+enum rmav_mem { RMAV_HOST = 0, RMAV_DEVICE = 1 };
+enum rmav_layout { RMAV_SOA = 0, RMAV_AOS = 1 };
+enum rmav_action_mode {
+    RMAV_ACT_BUFFER = 0,    /* actions read from a caller buffer */
+    RMAV_ACT_RANDOM = 1,    /* uniform in [act_lo, act_hi) from the counter RNG, generated in-kernel */
+    RMAV_ACT_CONTROLLER = 2 /* the reference's geometric controller, evaluated in-kernel */
+};
+
+/* rmav_create flags */
+#define RMAV_F_AUTO_RESET 1u     /* VecEnv semantics: a done env is reset inside step; the returned
+                                    obs is the post-reset obs (baselines DummyVecEnv.step_wait) */
+#define RMAV_F_TRACK_EPISODES 2u /* keep per-env episode return/length (baselines Monitor) */
+
+/* Physics and controller constants; defaults are the literals in each reference __init__
+ * (rmav_default_params).  Doubles, so that e.g. dt is the same 0.01 the reference uses. */
+typedef struct rmav_params {
+    double mass;          /* quadrotor3d.py:45 */
+    double load_mass;     /* quadrotor3d_slungload.py:46 */
+    double dt;            /* quadrotor3d.py:46 */
+    double g;             /* gravity magnitude; g = (0,-g) or (0,0,-g)  quadrotor3d.py:47 */
+    double tether_length; /* quadrotor3d_slungload.py:58 / quadrotor2d_slungload.py:53 */
+    double pos_limit;     /* episode ends when |pos| > pos_limit (which body: see DESIGN.md) */
+    double vel_limit;     /* ... or |vel| > vel_limit */
+    double thrust_scale;  /* quadrotor2d.py:75 (10 for quad2d, 1 otherwise) */
+    int32_t clamp_thrust; /* quadrotor2d.py:76-77 (1 for quad2d) */
+    int32_t _pad;
+    double ref_pos[3];    /* controller set-point  quadrotor3d.py:51 */
+    double ref_vel[3];    /* quadrotor3d.py:52 */
+    double kp, kv, tau;   /* controller gains  quadrotor3d.py:143-145, quadrotor2d.py:116-118 */
+    double act_lo, act_hi; /* action Box bounds (quadrotor3d.py:70 etc.); used by RMAV_ACT_RANDOM only */
+} rmav_params;
+
+typedef struct rmav_ep_totals {
+    uint64_t episodes;   /* finished episodes since creation / last clear */
+    double return_sum;   /* sum of their returns */
+    uint64_t length_sum; /* sum of their lengths */
+} rmav_ep_totals;
+
+/* ---- library-level ------------------------------------------------------------------------- */
+int rmav_version(void);              /* returns RMAV_VERSION */
+const char *rmav_last_error(void);   /* thread-local, never NULL */
+int rmav_device_count(void);         /* number of visible GPUs, 0 if none (never negative) */
+int rmav_state_dim(int kind);        /* 5, 9, 10, 16; -1 for a bad kind */
+int rmav_action_dim(int kind);       /* 2, 2, 4, 4 */
+int rmav_algorithmic_bytes(int kind); /* bytes per env-step of SURVEY.md 8(d): 53, 85, 101, 149 */
+/* reading_2d selects how the unparsable quadrotor2d.py:95-98 is read: 'B' -> |p|>3 or |v|>2
+ * (default when 0 is passed), 'A' -> |p|>3 or |v|>10.  Ignored for other kinds. */
+int rmav_default_params(int kind, int reading_2d, rmav_params *out);
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* Creates n_envs envs of `kind` on GPU `device`; env i has global id env_id_base + i.  All envs are
+ * reset once (reset index 0), like the reference constructors (quadrotor3d.py:73-74).
+ * params may be NULL (defaults).  hip_stream may be NULL (the handle creates its own stream) or a
+ * hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream). */
+int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t seed,
+                uint64_t env_id_base, uint32_t flags, const rmav_params *params, void *hip_stream);
+int rmav_destroy(rmav_handle h);
+/* Re-keys the RNG and rewinds the reset / step counters (gym Env.seed).  Does not touch state. */
+int rmav_seed(rmav_handle h, uint64_t seed);
+int rmav_get_params(rmav_handle h, rmav_params *out);
+int rmav_set_params(rmav_handle h, const rmav_params *in);
+int64_t rmav_num_envs(rmav_handle h); /* < 0 on a bad handle */
+int rmav_sync(rmav_handle h);         /* waits for everything enqueued on the handle's stream */
+
+/* ---- the hot path -------------------------------------------------------------------------- */
+/* Reset every env (fresh U[-1,1) state); steps_beyond_done is NOT cleared (the reference's reset
+ * does not).  obs_out (nS*N floats) may be NULL. */
+int rmav_reset(rmav_handle h, float *obs_out, int mem, int layout);
+
+/* One step of all N envs.  actions: nA*N floats.  Outputs (each may be NULL): obs_out nS*N floats,
+ * rew_out N floats, done_out N bytes (0/1). */
+int rmav_step(rmav_handle h, const float *actions, float *obs_out, float *rew_out,
+              uint8_t *done_out, int mem, int layout);
+
+/* Geometric controller: actions_out (nA*N floats) <- control(state). */
+int rmav_control(rmav_handle h, float *actions_out, int mem, int layout);
+
+/* n_steps steps of all N envs.  fused != 0: one kernel launch with the state held in registers
+ * across the steps; fused == 0: n_steps launches of the single-step kernel (same results).
+ * actions_in: [n_steps][nA][N] for RMAV_ACT_BUFFER, otherwise ignored (may be NULL).
+ * Optional trajectory outputs: actions_out [n_steps][nA][N], obs_out [n_steps][nS][N] (obs after
+ * each step, post auto-reset), rew_out [n_steps][N], done_out [n_steps][N]. */
+int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in,
+                 float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
+                 int layout, int fused);
+
+/* ---- state access (also the env checkpoint) ------------------------------------------------ */
+int rmav_get_state(rmav_handle h, float *out, int mem, int layout);      /* nS*N floats */
+int rmav_set_state(rmav_handle h, const float *in, int mem, int layout);
+int rmav_get_sbd(rmav_handle h, int32_t *out, int mem); /* steps_beyond_done per env, -1 = None */
+int rmav_set_sbd(rmav_handle h, const int32_t *in, int mem);
+int rmav_get_reset_counts(rmav_handle h, uint32_t *out, int mem); /* resets drawn so far per env */
+int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem);
+int rmav_get_step_count(rmav_handle h, uint64_t *out); /* global step counter t */
+int rmav_set_step_count(rmav_handle h, uint64_t t);
+
+/* ---- episode statistics (needs RMAV_F_TRACK_EPISODES) -------------------------------------- */
+int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear); /* synchronises */
+/* Per-env return / length of the most recently finished episode (0 / 0 if none yet) and of the
+ * running episode.  Any pointer may be NULL.  This is the payload of the per-rollout all-gather. */
+int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length,
+                         float *cur_return, int32_t *cur_length, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMAV_H */

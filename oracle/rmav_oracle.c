@@ -1,0 +1,517 @@
+/* rmav_oracle.c - fp64 CPU restatement of reinmav-gym's native quadrotor step()/control()/reset().
+ *
+ * TEST INFRASTRUCTURE ONLY - see rmav_oracle.h.  Reference line citations are relative to
+ * gym_reinmav/envs/native/ of the reference repository.
+ */
+#include "rmav_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+static const int k_state_dim[4] = {5, 9, 10, 16};
+static const int k_action_dim[4] = {2, 2, 4, 4};
+
+int oracle_state_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : k_state_dim[kind]; }
+int oracle_action_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : k_action_dim[kind]; }
+
+int oracle_default_params(int kind, int reading_2d, oracle_params *p) {
+    if (kind < 0 || kind > 3 || !p) return -1;
+    memset(p, 0, sizeof(*p));
+    p->mass = 1.0;      /* quadrotor3d.py:45, quadrotor2d.py:44 */
+    p->load_mass = 0.1; /* quadrotor3d_slungload.py:46, quadrotor2d_slungload.py:45 */
+    p->dt = 0.01;       /* quadrotor3d.py:46 */
+    p->g = 9.8;         /* quadrotor3d.py:47 g=(0,0,-9.8); quadrotor2d.py:46 g=(0,-9.8) */
+    p->thrust_scale = 1.0;
+    p->clamp_thrust = 0;
+    p->kp = -5.0; /* quadrotor3d.py:143, quadrotor2d.py:116 */
+    p->kv = -4.0; /* quadrotor3d.py:144, quadrotor2d.py:117 */
+    switch (kind) {
+    case ORACLE_QUAD2D:
+        /* quadrotor2d.py:95-98 (does not parse as shipped; see ref_harness.py).
+         * reading B: |p|>3.0 or |v|>10.0 or |v|>vel_threshold(2.0)  ==  |p|>3 or |v|>2
+         * reading A: |p|>3.0 or |v|>10.0 */
+        p->pos_limit = 3.0;
+        p->vel_limit = (reading_2d == 'A') ? 10.0 : 2.0;
+        p->thrust_scale = 10.0; /* quadrotor2d.py:75 */
+        p->clamp_thrust = 1;    /* quadrotor2d.py:76-77 */
+        p->tau = 0.1;           /* quadrotor2d.py:118 */
+        break;
+    case ORACLE_QUAD2D_SL:
+        p->tether_length = 0.5; /* quadrotor2d_slungload.py:53 */
+        p->pos_limit = 2.0;     /* quadrotor2d_slungload.py:56 */
+        p->vel_limit = 10.0;    /* quadrotor2d_slungload.py:57 */
+        p->tau = 0.1;           /* quadrotor2d_slungload.py:159 */
+        break;
+    case ORACLE_QUAD3D:
+        p->pos_limit = 3.0;  /* quadrotor3d.py:55 */
+        p->vel_limit = 10.0; /* quadrotor3d.py:56 */
+        p->ref_pos[2] = 2.0; /* quadrotor3d.py:51 */
+        p->tau = 0.3;        /* quadrotor3d.py:145 */
+        break;
+    case ORACLE_QUAD3D_SL:
+        p->tether_length = 1.5; /* quadrotor3d_slungload.py:58 */
+        p->pos_limit = 3.0;     /* quadrotor3d_slungload.py:55 */
+        p->vel_limit = 10.0;    /* quadrotor3d_slungload.py:56 */
+        p->ref_pos[2] = 1.0;    /* quadrotor3d_slungload.py:52 */
+        p->tau = 0.3;           /* quadrotor3d_slungload.py:187 */
+        break;
+    }
+    return 0;
+}
+
+/* ---- pyquaternion semantics used by the 3-D files (published 0.9.x algorithm) ---------------- */
+
+/* Quaternion._normalise(): q <- q/|q| unless |1-|q|^2| < 1e-14 or |q| == 0. */
+static void quat_normalise(const double q[4], double out[4]) {
+    double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!(fabs(1.0 - n2) < 1e-14)) {
+        double n = sqrt(n2);
+        if (n > 0) {
+            for (int i = 0; i < 4; ++i) out[i] = q[i] / n;
+            return;
+        }
+    }
+    for (int i = 0; i < 4; ++i) out[i] = q[i];
+}
+
+/* Quaternion.rotation_matrix.dot([0,0,1]) for an already-normalised q: third column of
+ * (Q . Qbar^T)[1:,1:], summed in the k=0..3 order np.dot uses. */
+static void quat_body_z(const double q[4], double b3[3]) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    b3[0] = x * z + w * y + (-z) * (-x) + y * w;
+    b3[1] = y * z + z * y + w * (-x) + (-x) * w;
+    b3[2] = z * z + (-y) * y + x * (-x) + w * w;
+}
+
+/* Quaternion.__mul__: _q_matrix(a) . b  (Hamilton product). */
+static void quat_mul(const double a[4], const double b[4], double o[4]) {
+    double w = a[0], x = a[1], y = a[2], z = a[3];
+    o[0] = w * b[0] + (-x) * b[1] + (-y) * b[2] + (-z) * b[3];
+    o[1] = x * b[0] + w * b[1] + (-z) * b[2] + y * b[3];
+    o[2] = y * b[0] + z * b[1] + w * b[2] + (-x) * b[3];
+    o[3] = z * b[0] + (-y) * b[1] + x * b[2] + w * b[3];
+}
+
+/* Quaternion.derivative(rate) = 0.5 * self * Quaternion(vector=rate). */
+static void quat_derivative(const double qn[4], const double rate[3], double o[4]) {
+    double half[4] = {0.5, 0.0, 0.0, 0.0}, h[4], r[4] = {0.0, rate[0], rate[1], rate[2]};
+    quat_mul(half, qn, h);
+    quat_mul(h, r, o);
+}
+
+/* Quaternion(matrix=R): validation (rtol 1e-5, atol 1e-8) then the 4-branch trace method on R^T.
+ * Returns 0 on success, -1 where pyquaternion raises ValueError (output filled with NaN). */
+static int quat_from_matrix(const double R[3][3], double q[4]) {
+    /* np.allclose(R.R^T, I) and np.isclose(det, 1) */
+    int ok = 1;
+    for (int i = 0; i < 3 && ok; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = R[i][0] * R[j][0] + R[i][1] * R[j][1] + R[i][2] * R[j][2];
+            double e = (i == j) ? 1.0 : 0.0;
+            if (!(fabs(v - e) <= 1e-8 + 1e-5 * fabs(e))) ok = 0;
+        }
+    double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) -
+                 R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                 R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+    if (!(fabs(det - 1.0) <= 1e-8 + 1e-5)) ok = 0;
+    if (!ok) {
+        q[0] = q[1] = q[2] = q[3] = NAN;
+        return -1;
+    }
+    double m[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) m[i][j] = R[j][i];
+    double t;
+    if (m[2][2] < 0) {
+        if (m[0][0] > m[1][1]) {
+            t = 1 + m[0][0] - m[1][1] - m[2][2];
+            q[0] = m[1][2] - m[2][1]; q[1] = t; q[2] = m[0][1] + m[1][0]; q[3] = m[2][0] + m[0][2];
+        } else {
+            t = 1 - m[0][0] + m[1][1] - m[2][2];
+            q[0] = m[2][0] - m[0][2]; q[1] = m[0][1] + m[1][0]; q[2] = t; q[3] = m[1][2] + m[2][1];
+        }
+    } else {
+        if (m[0][0] < -m[1][1]) {
+            t = 1 - m[0][0] - m[1][1] + m[2][2];
+            q[0] = m[0][1] - m[1][0]; q[1] = m[2][0] + m[0][2]; q[2] = m[1][2] + m[2][1]; q[3] = t;
+        } else {
+            t = 1 + m[0][0] + m[1][1] + m[2][2];
+            q[0] = t; q[1] = m[1][2] - m[2][1]; q[2] = m[2][0] - m[0][2]; q[3] = m[0][1] - m[1][0];
+        }
+    }
+    double k = 0.5 / sqrt(t);
+    for (int i = 0; i < 4; ++i) q[i] *= k;
+    return 0;
+}
+
+static double norm2(const double *v, int n) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += v[i] * v[i];
+    return sqrt(s);
+}
+static double inner(const double *a, const double *b, int n) {
+    double s = 0;
+    for (int i = 0; i < n; ++i) s += a[i] * b[i];
+    return s;
+}
+
+/* Reward / steps_beyond_done state machine, identical in all four files
+ * (quadrotor3d.py:112-122, quadrotor3d_slungload.py:155-165, quadrotor2d.py:101-111,
+ * quadrotor2d_slungload.py:142-152).  reset() never clears steps_beyond_done, so the terminal
+ * reward 1.0 is paid once per env object lifetime. */
+static double reward_machine(int done, double dist, int *sbd) {
+    if (!done) return -dist;
+    if (*sbd < 0) {
+        *sbd = 0;
+        return 1.0;
+    }
+    *sbd += 1;
+    return 0.0;
+}
+
+/* ---- Quadrotor3D.step  quadrotor3d.py:81-124 --------------------------------------------------- */
+static void step_quad3d(const oracle_params *p, const double *s, const double *a, double *o,
+                        double *reward, int *done, int *sbd) {
+    const double dt = p->dt;
+    double thrust = a[0];                       /* :82 */
+    const double *w = a + 1;                    /* :83 */
+    double pos[3] = {s[0], s[1], s[2]};         /* :89 */
+    double att[4] = {s[3], s[4], s[5], s[6]};   /* :90 */
+    double vel[3] = {s[7], s[8], s[9]};         /* :91 */
+    double g[3] = {0.0, 0.0, -p->g};
+    double qn[4], b3[3], acc[3], qd[4];
+    quat_normalise(att, qn);                    /* :96 rotation_matrix normalises the Quaternion */
+    quat_body_z(qn, b3);
+    for (int i = 0; i < 3; ++i) acc[i] = thrust / p->mass * b3[i] + g[i];                 /* :96 */
+    for (int i = 0; i < 3; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt;   /* :98 */
+    for (int i = 0; i < 3; ++i) vel[i] = vel[i] + acc[i] * dt;                            /* :99 */
+    quat_derivative(qn, w, qd);                 /* :101 (normalised q) */
+    for (int i = 0; i < 4; ++i) att[i] = att[i] + qd[i] * dt; /* :102 (raw att) */
+    o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2];
+    o[3] = att[0]; o[4] = att[1]; o[5] = att[2]; o[6] = att[3];
+    o[7] = vel[0]; o[8] = vel[1]; o[9] = vel[2];
+    double np_ = norm2(pos, 3), nv = norm2(vel, 3);
+    *done = (np_ < -p->pos_limit) || (np_ > p->pos_limit) || (nv < -p->vel_limit) ||
+            (nv > p->vel_limit);                /* :106-110 */
+    *reward = reward_machine(*done, np_, sbd);  /* :112-122 */
+}
+
+/* ---- Quadrotor3DSlungload.step  quadrotor3d_slungload.py:87-167 ------------------------------- */
+static void step_quad3d_sl(const oracle_params *p, const double *s, const double *a, double *o,
+                           double *reward, int *done, int *sbd) {
+    const double dt = p->dt, L = p->tether_length;
+    double thrust = a[0];
+    const double *w = a + 1;
+    double pos[3] = {s[0], s[1], s[2]};
+    double att[4] = {s[3], s[4], s[5], s[6]};
+    double vel[3] = {s[7], s[8], s[9]};
+    double lp[3] = {s[10], s[11], s[12]};
+    double lv[3] = {s[13], s[14], s[15]};
+    double g[3] = {0.0, 0.0, -p->g};
+    double tv[3], u[3], qn[4], b3[3], acc[3], qd[4], la[3];
+    for (int i = 0; i < 3; ++i) tv[i] = lp[i] - pos[i];          /* :101 */
+    double d = norm2(tv, 3);
+    for (int i = 0; i < 3; ++i) u[i] = tv[i] / d;                /* :102 */
+    quat_normalise(att, qn);
+    quat_body_z(qn, b3);
+    if (d >= L) {                                                /* :104 taut */
+        double thr_vec[3], tmp[3], T[3], ldir[3], dlp[3], dv[3];
+        for (int i = 0; i < 3; ++i) thr_vec[i] = thrust * b3[i]; /* :109 */
+        double c = p->mass * L * inner(lv, lv, 3);
+        for (int i = 0; i < 3; ++i) tmp[i] = thr_vec[i] - c;     /* :110 vector - scalar */
+        double sc = inner(u, tmp, 3);
+        for (int i = 0; i < 3; ++i) la[i] = sc * u[i];
+        for (int i = 0; i < 3; ++i) la[i] = (1 / (p->mass + p->load_mass)) * la[i] + g[i]; /* :111 */
+        for (int i = 0; i < 3; ++i) lp[i] = lp[i] + lv[i] * dt + 0.5 * la[i] * dt * dt;    /* :112 */
+        for (int i = 0; i < 3; ++i) lv[i] = lv[i] + la[i] * dt;                            /* :113 */
+        for (int i = 0; i < 3; ++i) tmp[i] = -g[i] + la[i];
+        double tn = norm2(tmp, 3);
+        for (int i = 0; i < 3; ++i) T[i] = p->load_mass * tn * u[i];                       /* :115 */
+        for (int i = 0; i < 3; ++i) acc[i] = thrust / p->mass * b3[i] + g[i] + T[i] / p->mass; /* :118 */
+        for (int i = 0; i < 3; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt;
+        for (int i = 0; i < 3; ++i) vel[i] = vel[i] + acc[i] * dt;
+        quat_derivative(qn, w, qd);
+        for (int i = 0; i < 4; ++i) att[i] = att[i] + qd[i] * dt;                          /* :123 */
+        for (int i = 0; i < 3; ++i) dlp[i] = lp[i] - pos[i];
+        double dn = norm2(dlp, 3);
+        for (int i = 0; i < 3; ++i) ldir[i] = dlp[i] / dn;                                 /* :126 */
+        for (int i = 0; i < 3; ++i) lp[i] = pos[i] + ldir[i] * L;                          /* :127 */
+        for (int i = 0; i < 3; ++i) dv[i] = lv[i] - vel[i];
+        double pr = inner(dv, ldir, 3);
+        for (int i = 0; i < 3; ++i) lv[i] = lv[i] - pr * ldir[i];                          /* :128 */
+    } else {                                                     /* :131 slack */
+        for (int i = 0; i < 3; ++i) la[i] = g[i];
+        for (int i = 0; i < 3; ++i) lp[i] = lp[i] + lv[i] * dt + 0.5 * la[i] * dt * dt;    /* :136 */
+        for (int i = 0; i < 3; ++i) lv[i] = lv[i] + la[i] * dt;
+        for (int i = 0; i < 3; ++i) acc[i] = thrust / p->mass * b3[i] + g[i];              /* :140 */
+        for (int i = 0; i < 3; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt;
+        for (int i = 0; i < 3; ++i) vel[i] = vel[i] + acc[i] * dt;
+        quat_derivative(qn, w, qd);
+        for (int i = 0; i < 4; ++i) att[i] = att[i] + qd[i] * dt;
+    }
+    o[0] = pos[0]; o[1] = pos[1]; o[2] = pos[2];
+    o[3] = att[0]; o[4] = att[1]; o[5] = att[2]; o[6] = att[3];
+    o[7] = vel[0]; o[8] = vel[1]; o[9] = vel[2];
+    o[10] = lp[0]; o[11] = lp[1]; o[12] = lp[2];
+    o[13] = lv[0]; o[14] = lv[1]; o[15] = lv[2];
+    double nlp = norm2(lp, 3), nv = norm2(vel, 3);
+    *done = (nlp < -p->pos_limit) || (nlp > p->pos_limit) || (nv < -p->vel_limit) ||
+            (nv > p->vel_limit);                 /* :149-153 load position, quad velocity */
+    *reward = reward_machine(*done, nlp, sbd);   /* :155-165 reward -|load_pos| */
+}
+
+/* ---- Quadrotor2D.step  quadrotor2d.py:74-113 ---------------------------------------------------- */
+static void step_quad2d(const oracle_params *p, const double *s, const double *a, double *o,
+                        double *reward, int *done, int *sbd) {
+    const double dt = p->dt;
+    double thrust = p->thrust_scale * a[0];               /* :75 */
+    if (p->clamp_thrust && thrust < 0.0) thrust = 0.0;    /* :76-77 */
+    double w = a[1];                                      /* :78 */
+    double pos[2] = {s[0], s[1]}, att = s[2], vel[2] = {s[3], s[4]};
+    double g[2] = {0.0, -p->g};
+    double dir[2] = {cos(att + M_PI / 2), sin(att + M_PI / 2)};
+    double acc[2];
+    for (int i = 0; i < 2; ++i) acc[i] = thrust / p->mass * dir[i] + g[i];               /* :88 */
+    for (int i = 0; i < 2; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt;  /* :89 */
+    for (int i = 0; i < 2; ++i) vel[i] = vel[i] + acc[i] * dt;                           /* :90 */
+    att = att + w * dt;                                                                  /* :91 */
+    o[0] = pos[0]; o[1] = pos[1]; o[2] = att; o[3] = vel[0]; o[4] = vel[1];
+    double np_ = norm2(pos, 2), nv = norm2(vel, 2);
+    *done = (np_ > p->pos_limit) || (nv > p->vel_limit);  /* :95-98 under the chosen reading */
+    *reward = reward_machine(*done, np_, sbd);            /* :101-111 */
+}
+
+/* ---- Quadrotor2DSlungload.step  quadrotor2d_slungload.py:79-154 (velocity-first updates) ------- */
+static void step_quad2d_sl(const oracle_params *p, const double *s, const double *a, double *o,
+                           double *reward, int *done, int *sbd) {
+    const double dt = p->dt, L = p->tether_length;
+    double thrust = p->thrust_scale * a[0];               /* :80 (scale 1: no x10, no clamp) */
+    if (p->clamp_thrust && thrust < 0.0) thrust = 0.0;
+    double w = a[1];
+    double pos[2] = {s[0], s[1]}, att = s[2], vel[2] = {s[3], s[4]};
+    double lp[2] = {s[5], s[6]}, lv[2] = {s[7], s[8]};
+    double g[2] = {0.0, -p->g};
+    double tv[2], u[2], la[2], acc[2];
+    for (int i = 0; i < 2; ++i) tv[i] = lp[i] - pos[i];   /* :92 */
+    double d = norm2(tv, 2);
+    for (int i = 0; i < 2; ++i) u[i] = tv[i] / d;         /* :93 */
+    double dir[2] = {cos(att + M_PI / 2), sin(att + M_PI / 2)};
+    if (d >= L) {                                         /* :95 taut */
+        double thr_vec[2], tmp[2], T[2], ldir[2], dlp[2], dv[2];
+        for (int i = 0; i < 2; ++i) thr_vec[i] = thrust * dir[i];                          /* :96 */
+        double c = p->mass * L * inner(lv, lv, 2);
+        for (int i = 0; i < 2; ++i) tmp[i] = thr_vec[i] - c;                               /* :97 */
+        double sc = inner(u, tmp, 2);
+        for (int i = 0; i < 2; ++i) la[i] = sc * u[i];
+        for (int i = 0; i < 2; ++i) la[i] = (1 / (p->mass + p->load_mass)) * la[i] + g[i]; /* :98 */
+        for (int i = 0; i < 2; ++i) lv[i] = lv[i] + la[i] * dt;                            /* :99 */
+        for (int i = 0; i < 2; ++i) lp[i] = lp[i] + lv[i] * dt + 0.5 * la[i] * dt * dt;    /* :100 */
+        for (int i = 0; i < 2; ++i) tmp[i] = -g[i] + la[i];
+        double tn = norm2(tmp, 2);
+        for (int i = 0; i < 2; ++i) T[i] = p->load_mass * tn * u[i];                       /* :102 */
+        for (int i = 0; i < 2; ++i) acc[i] = thrust / p->mass * dir[i] + g[i] + T[i] / p->mass; /* :107 */
+        for (int i = 0; i < 2; ++i) vel[i] = vel[i] + acc[i] * dt;                         /* :108 */
+        for (int i = 0; i < 2; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt; /* :109 */
+        att = att + w * dt;
+        for (int i = 0; i < 2; ++i) dlp[i] = lp[i] - pos[i];
+        double dn = norm2(dlp, 2);
+        for (int i = 0; i < 2; ++i) ldir[i] = dlp[i] / dn;                                 /* :113 */
+        for (int i = 0; i < 2; ++i) lp[i] = pos[i] + ldir[i] * L;                          /* :114 */
+        for (int i = 0; i < 2; ++i) dv[i] = lv[i] - vel[i];
+        double pr = inner(dv, ldir, 2);
+        for (int i = 0; i < 2; ++i) lv[i] = lv[i] - pr * ldir[i];                          /* :115 */
+    } else {                                              /* :118 slack */
+        for (int i = 0; i < 2; ++i) la[i] = g[i];
+        for (int i = 0; i < 2; ++i) lv[i] = lv[i] + la[i] * dt;                            /* :124 */
+        for (int i = 0; i < 2; ++i) lp[i] = lp[i] + lv[i] * dt + 0.5 * la[i] * dt * dt;    /* :125 */
+        for (int i = 0; i < 2; ++i) acc[i] = thrust / p->mass * dir[i] + g[i];             /* :128 */
+        for (int i = 0; i < 2; ++i) vel[i] = vel[i] + acc[i] * dt;
+        for (int i = 0; i < 2; ++i) pos[i] = pos[i] + vel[i] * dt + 0.5 * acc[i] * dt * dt;
+        att = att + w * dt;
+    }
+    o[0] = pos[0]; o[1] = pos[1]; o[2] = att; o[3] = vel[0]; o[4] = vel[1];
+    o[5] = lp[0]; o[6] = lp[1]; o[7] = lv[0]; o[8] = lv[1];
+    double nlp = norm2(lp, 2), nlv = norm2(lv, 2);
+    *done = (nlp < -p->pos_limit) || (nlp > p->pos_limit) || (nlv < -p->vel_limit) ||
+            (nlv > p->vel_limit);                      /* :136-140 load position, load velocity */
+    *reward = reward_machine(*done, norm2(pos, 2), sbd); /* :142-152 reward -|quad pos| */
+}
+
+int oracle_step(int kind, const oracle_params *p, const double *s, const double *a, double *s_out,
+                double *reward, int *done, int *sbd) {
+    switch (kind) {
+    case ORACLE_QUAD2D: step_quad2d(p, s, a, s_out, reward, done, sbd); return 0;
+    case ORACLE_QUAD2D_SL: step_quad2d_sl(p, s, a, s_out, reward, done, sbd); return 0;
+    case ORACLE_QUAD3D: step_quad3d(p, s, a, s_out, reward, done, sbd); return 0;
+    case ORACLE_QUAD3D_SL: step_quad3d_sl(p, s, a, s_out, reward, done, sbd); return 0;
+    }
+    return -1;
+}
+
+/* ---- Quadrotor3D.control  quadrotor3d.py:126-180 (= quadrotor3d_slungload.py:169-226) ---------- */
+static int control_3d(const oracle_params *p, const double *s, double *a_out) {
+    double pos[3] = {s[0], s[1], s[2]};
+    double att[4] = {s[3], s[4], s[5], s[6]};
+    double vel[3] = {s[7], s[8], s[9]};
+    double g[3] = {0.0, 0.0, -p->g};
+    double ad[3];
+    for (int i = 0; i < 3; ++i) {
+        double ep = pos[i] - p->ref_pos[i], ev = vel[i] - p->ref_vel[i]; /* :155-156 */
+        double fb = p->kp * ep + p->kv * ev;                             /* :160 */
+        ad[i] = 0.0 + fb - g[i];                                         /* :162 */
+    }
+    /* acc2quat :127-141 */
+    double n = norm2(ad, 3), zb[3], xb[3], yb[3];
+    for (int i = 0; i < 3; ++i) zb[i] = ad[i] / n;
+    /* np.cross((0,1,0), zb) */
+    xb[0] = 1.0 * zb[2] - 0.0 * zb[1];
+    xb[1] = 0.0 * zb[0] - 0.0 * zb[2];
+    xb[2] = 0.0 * zb[1] - 1.0 * zb[0];
+    double nx = norm2(xb, 3);
+    for (int i = 0; i < 3; ++i) xb[i] = xb[i] / nx;
+    yb[0] = zb[1] * xb[2] - zb[2] * xb[1];
+    yb[1] = zb[2] * xb[0] - zb[0] * xb[2];
+    yb[2] = zb[0] * xb[1] - zb[1] * xb[0];
+    double nz = norm2(zb, 3);
+    for (int i = 0; i < 3; ++i) zb[i] = zb[i] / nz;
+    double R[3][3] = {{xb[0], yb[0], zb[0]}, {xb[1], yb[1], zb[1]}, {xb[2], yb[2], zb[2]}};
+    double qdes[4];
+    int rc = quat_from_matrix(R, qdes); /* :139 */
+    double conj[4] = {att[0], -att[1], -att[2], -att[3]}, qe[4];
+    quat_mul(conj, qdes, qe);           /* :169 conj(raw q) * q_des */
+    double sg = (qe[0] > 0) ? 1.0 : ((qe[0] < 0) ? -1.0 : (qe[0] == 0 ? 0.0 : NAN));
+    double k = (2 / p->tau) * sg;       /* :173 */
+    double qn[4], b3[3];
+    quat_normalise(att, qn);
+    quat_body_z(qn, b3);
+    a_out[0] = ad[0] * b3[0] + ad[1] * b3[1] + ad[2] * b3[2]; /* :176 */
+    a_out[1] = k * qe[1];
+    a_out[2] = k * qe[2];
+    a_out[3] = k * qe[3];
+    return rc;
+}
+
+/* ---- Quadrotor2D.control  quadrotor2d.py:115-138 (= quadrotor2d_slungload.py:156-183) ---------- */
+static int control_2d(const oracle_params *p, const double *s, double *a_out) {
+    double ad[2];
+    double g9[2] = {0.0, p->g};
+    for (int i = 0; i < 2; ++i) {
+        double ep = s[i] - p->ref_pos[i], ev = s[3 + i] - p->ref_vel[i]; /* :127-128 */
+        ad[i] = p->kp * ep + p->kv * ev + g9[i];                         /* :130 */
+    }
+    double th_d = atan2(ad[1], ad[0]) - M_PI / 2; /* :131 */
+    double e = s[2] - th_d;                       /* :132 */
+    a_out[1] = (-1 / p->tau) * e;                 /* :133 */
+    a_out[0] = p->mass * norm2(ad, 2);            /* :134 */
+    return 0;
+}
+
+int oracle_control(int kind, const oracle_params *p, const double *s, double *a_out) {
+    switch (kind) {
+    case ORACLE_QUAD2D:
+    case ORACLE_QUAD2D_SL: return control_2d(p, s, a_out);
+    case ORACLE_QUAD3D:
+    case ORACLE_QUAD3D_SL: return control_3d(p, s, a_out);
+    }
+    return -1;
+}
+
+/* ---- Philox4x32-10 (Salmon et al., SC'11; Random123 constants) -------------------------------- */
+void oracle_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+float oracle_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+/* Counter layout (specification shared with the HIP path, see include/rmav.h "RNG streams"):
+ *   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, c2, (tag << 24) | (hi16 << 8) | block)
+ *   reset : tag 1, c2 = episode index, hi16 = 0, block j yields components 4j..4j+3
+ *   action: tag 2, c2 = t_lo, hi16 = bits 32..47 of t, block 0 */
+void oracle_reset_state(int kind, uint64_t seed, uint64_t env_id, uint32_t episode, float *s_out) {
+    int nS = k_state_dim[kind];
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int j = 0; j * 4 < nS; ++j) {
+        uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode,
+                           (1u << 24) | (uint32_t)j};
+        uint32_t r[4];
+        oracle_philox4x32_10(ctr, key, r);
+        for (int i = 0; i < 4 && j * 4 + i < nS; ++i)
+            s_out[j * 4 + i] = 2.0f * oracle_u01(r[i]) - 1.0f; /* exact in fp32 */
+    }
+}
+
+void oracle_random_action(int kind, uint64_t seed, uint64_t env_id, uint64_t t, float lo, float hi,
+                          float *a_out) {
+    int nA = k_action_dim[kind];
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
+                       (2u << 24) | ((uint32_t)((t >> 32) & 0xFFFFu) << 8)};
+    uint32_t r[4];
+    oracle_philox4x32_10(ctr, key, r);
+    for (int i = 0; i < nA; ++i) a_out[i] = fmaf(hi - lo, oracle_u01(r[i]), lo);
+}
+
+/* ---- batched drivers ---------------------------------------------------------------------------- */
+int oracle_batch_step(int kind, const oracle_params *p, int64_t n, double *s, const double *a,
+                      double *reward, uint8_t *done, int32_t *sbd, int round_f32) {
+    if (kind < 0 || kind > 3) return -1;
+    int nS = k_state_dim[kind], nA = k_action_dim[kind];
+    for (int64_t e = 0; e < n; ++e) {
+        double o[16], r;
+        int d, sb = sbd[e];
+        oracle_step(kind, p, s + e * nS, a + e * nA, o, &r, &d, &sb);
+        for (int i = 0; i < nS; ++i) s[e * nS + i] = round_f32 ? (double)(float)o[i] : o[i];
+        reward[e] = round_f32 ? (double)(float)r : r;
+        done[e] = (uint8_t)d;
+        sbd[e] = sb;
+    }
+    return 0;
+}
+
+int64_t oracle_rollout_random(int kind, const oracle_params *p, int64_t n, int64_t steps,
+                              uint64_t seed, uint64_t env_id_base, float lo, float hi, float *state,
+                              int32_t *sbd, uint32_t *episode, uint64_t t0, double *ret_sum,
+                              int64_t *n_done) {
+    if (kind < 0 || kind > 3) return -1;
+    int nS = k_state_dim[kind], nA = k_action_dim[kind];
+    double acc = 0.0;
+    int64_t nd = 0;
+    for (int64_t k = 0; k < steps; ++k) {
+        for (int64_t e = 0; e < n; ++e) {
+            float af[4];
+            double s[16], a[4], o[16], r;
+            int d, sb = sbd[e];
+            oracle_random_action(kind, seed, env_id_base + (uint64_t)e, t0 + (uint64_t)k, lo, hi, af);
+            for (int i = 0; i < nA; ++i) a[i] = af[i];
+            for (int i = 0; i < nS; ++i) s[i] = state[e * nS + i];
+            oracle_step(kind, p, s, a, o, &r, &d, &sb);
+            sbd[e] = sb;
+            acc += r;
+            if (d) {
+                ++nd;
+                oracle_reset_state(kind, seed, env_id_base + (uint64_t)e, episode[e], state + e * nS);
+                episode[e] += 1;
+            } else {
+                for (int i = 0; i < nS; ++i) state[e * nS + i] = (float)o[i];
+            }
+        }
+    }
+    if (ret_sum) *ret_sum += acc;
+    if (n_done) *n_done += nd;
+    return n * steps;
+}

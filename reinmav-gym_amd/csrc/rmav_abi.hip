@@ -1,0 +1,646 @@
+// rmav_abi.hip - the C ABI of include/rmav.h: handle management, launches, host/device staging.
+// There is deliberately no CPU implementation in this library: without a GPU rmav_create fails.
+#include "../../include/rmav.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "rmav_derive.hpp"
+#include "rmav_kernels.hpp"
+
+using namespace rmav;
+
+namespace {
+
+thread_local char g_err[768] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RMAV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+constexpr uint32_t kMagic = 0x524d4156u;  // 'RMAV'
+constexpr int kStateDim[4] = {5, 9, 10, 16};
+constexpr int kActionDim[4] = {2, 2, 4, 4};
+
+}  // namespace
+
+struct rmav_env_s {
+    uint32_t magic;
+    int kind;
+    int64_t n;
+    int device;
+    uint64_t seed;
+    uint64_t env_base;
+    uint32_t flags;
+    rmav_params params;
+    hipStream_t stream;
+    bool own_stream;
+    uint64_t t;  // global step counter
+    // device-resident env data
+    float *state;
+    int32_t *sbd;
+    uint32_t *reset_cnt;
+    float *ep_ret, *last_ret;
+    int32_t *ep_len, *last_len;
+    Totals *totals;
+    // scratch for host-pointer calls and layout conversion (grown on demand)
+    void *scratch;
+    size_t scratch_bytes;
+};
+
+namespace {
+
+bool valid(rmav_handle h) { return h && h->magic == kMagic; }
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+#define CHECK_HANDLE(h)                                                                            \
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");                           \
+    DeviceGuard guard_(h->device);                                                                 \
+    if (!guard_.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", h->device)
+
+int check_params(const rmav_params &q) {
+    if (!(q.mass > 0) || !(q.dt > 0) || !(q.tau != 0) || !(q.mass + q.load_mass > 0))
+        return fail(RMAV_ERR_INVALID, "rmav_params: mass, dt must be > 0 and tau != 0");
+    return RMAV_OK;
+}
+
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+int ensure_scratch(rmav_handle h, size_t bytes) {
+    if (bytes <= h->scratch_bytes) return RMAV_OK;
+    if (h->scratch) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipFree(h->scratch));
+        h->scratch = nullptr;
+        h->scratch_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2);
+    if (hipMalloc(&h->scratch, want) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(RMAV_ERR_ALLOC, "hipMalloc(%zu) for scratch failed", want);
+    }
+    h->scratch_bytes = want;
+    return RMAV_OK;
+}
+
+template <int K, int MODE>
+int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
+    using R = typename Env<K>::R;
+    const ParamsT<R> p = derive<R>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params);
+    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(kBlock), 0, h->stream, a, p, pc);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs &a) {
+    switch (mode) {
+    case RMAV_ACT_BUFFER: return launch_rollout_km<K, ACT_BUFFER>(h, a);
+    case RMAV_ACT_RANDOM: return launch_rollout_km<K, ACT_RANDOM>(h, a);
+    case RMAV_ACT_CONTROLLER: return launch_rollout_km<K, ACT_CONTROLLER>(h, a);
+    }
+    return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
+}
+
+int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
+    switch (h->kind) {
+    case RMAV_QUAD2D: return launch_rollout_k<QUAD2D>(h, mode, a);
+    case RMAV_QUAD2D_SL: return launch_rollout_k<QUAD2D_SL>(h, mode, a);
+    case RMAV_QUAD3D: return launch_rollout_k<QUAD3D>(h, mode, a);
+    case RMAV_QUAD3D_SL: return launch_rollout_k<QUAD3D_SL>(h, mode, a);
+    }
+    return fail(RMAV_ERR_INVALID, "bad kind");
+}
+
+RolloutArgs base_args(rmav_handle h) {
+    RolloutArgs a;
+    memset(&a, 0, sizeof(a));
+    a.state = h->state;
+    a.n = h->n;
+    a.sbd = h->sbd;
+    a.reset_cnt = h->reset_cnt;
+    a.ep_ret = h->ep_ret;
+    a.ep_len = h->ep_len;
+    a.last_ret = h->last_ret;
+    a.last_len = h->last_len;
+    a.totals = h->totals;
+    a.seed = h->seed;
+    a.env_base = h->env_base;
+    a.t0 = h->t;
+    a.n_steps = 1;
+    a.flags = h->flags & (F_AUTO_RESET | F_TRACK);
+    a.act_lo = (float)h->params.act_lo;
+    a.act_hi = (float)h->params.act_hi;
+    return a;
+}
+
+int launch_reset(rmav_handle h, float *obs_dev, int layout) {
+    const uint32_t fl = (h->flags & F_TRACK) | (layout == RMAV_AOS ? F_AOS : 0u);
+#define RMAV_RESET_CASE(KIND)                                                                      \
+    hipLaunchKernelGGL((k_reset<KIND>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,      \
+                       h->n, h->reset_cnt, h->ep_ret, h->ep_len, obs_dev, h->seed, h->env_base, fl)
+    switch (h->kind) {
+    case RMAV_QUAD2D: RMAV_RESET_CASE(QUAD2D); break;
+    case RMAV_QUAD2D_SL: RMAV_RESET_CASE(QUAD2D_SL); break;
+    case RMAV_QUAD3D: RMAV_RESET_CASE(QUAD3D); break;
+    case RMAV_QUAD3D_SL: RMAV_RESET_CASE(QUAD3D_SL); break;
+    }
+#undef RMAV_RESET_CASE
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+int launch_control(rmav_handle h, float *act_dev, int layout) {
+    const uint32_t fl = (layout == RMAV_AOS ? F_AOS : 0u);
+    const ParamsT<double> pc = derive<double>(h->params);
+#define RMAV_CTRL_CASE(KIND)                                                                       \
+    hipLaunchKernelGGL((k_control<KIND>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,    \
+                       h->n, act_dev, fl, pc)
+    switch (h->kind) {
+    case RMAV_QUAD2D: RMAV_CTRL_CASE(QUAD2D); break;
+    case RMAV_QUAD2D_SL: RMAV_CTRL_CASE(QUAD2D_SL); break;
+    case RMAV_QUAD3D: RMAV_CTRL_CASE(QUAD3D); break;
+    case RMAV_QUAD3D_SL: RMAV_CTRL_CASE(QUAD3D_SL); break;
+    }
+#undef RMAV_CTRL_CASE
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+int check_mem_layout(int mem, int layout) {
+    if (mem != RMAV_HOST && mem != RMAV_DEVICE) return fail(RMAV_ERR_INVALID, "mem must be RMAV_HOST or RMAV_DEVICE");
+    if (layout != RMAV_SOA && layout != RMAV_AOS) return fail(RMAV_ERR_INVALID, "layout must be RMAV_SOA or RMAV_AOS");
+    return RMAV_OK;
+}
+
+// Generic "copy a per-env array out of / into the handle".
+template <typename T> int copy_out(rmav_handle h, const T *dev, T *out, size_t count, int mem) {
+    if (!out) return fail(RMAV_ERR_INVALID, "output pointer is NULL");
+    if (mem == RMAV_DEVICE) {
+        HIP_TRY(hipMemcpyAsync(out, dev, count * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(out, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return RMAV_OK;
+}
+template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t count, int mem) {
+    if (!in) return fail(RMAV_ERR_INVALID, "input pointer is NULL");
+    if (mem == RMAV_DEVICE) {
+        HIP_TRY(hipMemcpyAsync(dev, in, count * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(dev, in, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return RMAV_OK;
+}
+
+void free_all(rmav_handle h) {
+    void *ptrs[] = {h->state, h->sbd, h->reset_cnt, h->ep_ret, h->last_ret, h->ep_len, h->last_len,
+                    h->totals, h->scratch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->magic = 0;
+    delete h;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int rmav_version(void) { return RMAV_VERSION; }
+
+const char *rmav_last_error(void) { return g_err; }
+
+int rmav_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n < 0 ? 0 : n;
+}
+
+int rmav_state_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : kStateDim[kind]; }
+int rmav_action_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : kActionDim[kind]; }
+
+int rmav_algorithmic_bytes(int kind) {
+    if (kind < 0 || kind > 3) return -1;
+    // read state + read action + write state + write reward (f32) + write done (u8)
+    return 4 * (2 * kStateDim[kind] + kActionDim[kind] + 1) + 1;
+}
+
+int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
+    if (kind < 0 || kind > 3) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (!p) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (reading_2d != 0 && reading_2d != 'A' && reading_2d != 'B')
+        return fail(RMAV_ERR_INVALID, "reading_2d must be 0, 'A' or 'B'");
+    memset(p, 0, sizeof(*p));
+    p->mass = 1.0;
+    p->load_mass = 0.1;
+    p->dt = 0.01;
+    p->g = 9.8;
+    p->thrust_scale = 1.0;
+    p->kp = -5.0;
+    p->kv = -4.0;
+    p->act_lo = -10.0;
+    p->act_hi = 10.0;
+    switch (kind) {
+    case RMAV_QUAD2D:
+        p->pos_limit = 3.0;
+        p->vel_limit = (reading_2d == 'A') ? 10.0 : 2.0;
+        p->thrust_scale = 10.0;
+        p->clamp_thrust = 1;
+        p->tau = 0.1;
+        break;
+    case RMAV_QUAD2D_SL:
+        p->tether_length = 0.5;
+        p->pos_limit = 2.0;
+        p->vel_limit = 10.0;
+        p->tau = 0.1;
+        break;
+    case RMAV_QUAD3D:
+        p->pos_limit = 3.0;
+        p->vel_limit = 10.0;
+        p->ref_pos[2] = 2.0;
+        p->tau = 0.3;
+        p->act_lo = 0.0;  // quadrotor3d.py:70 Box(low=0, high=10)
+        break;
+    case RMAV_QUAD3D_SL:
+        p->tether_length = 1.5;
+        p->pos_limit = 3.0;
+        p->vel_limit = 10.0;
+        p->ref_pos[2] = 1.0;
+        p->tau = 0.3;
+        break;
+    }
+    return RMAV_OK;
+}
+
+int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t seed,
+                uint64_t env_id_base, uint32_t flags, const rmav_params *params, void *hip_stream) {
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (kind < 0 || kind > 3) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) * kBlock)
+        return fail(RMAV_ERR_INVALID, "n_envs out of range: %lld", (long long)n_envs);
+    if (flags & ~(RMAV_F_AUTO_RESET | RMAV_F_TRACK_EPISODES))
+        return fail(RMAV_ERR_INVALID, "unknown flag bits 0x%x", flags);
+    const int ndev = rmav_device_count();
+    if (ndev <= 0) return fail(RMAV_ERR_NO_DEVICE, "no HIP device visible; librmav has no CPU path");
+    if (device < 0 || device >= ndev) return fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    rmav_params pr;
+    if (params) pr = *params;
+    else rmav_default_params(kind, 0, &pr);
+    if (int rc = check_params(pr)) return rc;
+
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
+
+    rmav_handle h = new (std::nothrow) rmav_env_s();
+    if (!h) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    memset(h, 0, sizeof(*h));
+    h->magic = kMagic;
+    h->kind = kind;
+    h->n = n_envs;
+    h->device = device;
+    h->seed = seed;
+    h->env_base = env_id_base;
+    h->flags = flags;
+    h->params = pr;
+    if (hip_stream) {
+        h->stream = (hipStream_t)hip_stream;
+        h->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            free_all(h);
+            return fail(RMAV_ERR_HIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    const size_t n = (size_t)n_envs;
+    const int nS = kStateDim[kind];
+    bool ok = hipMalloc((void **)&h->state, n * nS * sizeof(float)) == hipSuccess &&
+              hipMalloc((void **)&h->sbd, n * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc((void **)&h->reset_cnt, n * sizeof(uint32_t)) == hipSuccess &&
+              hipMalloc((void **)&h->totals, sizeof(Totals)) == hipSuccess;
+    if (ok && (flags & RMAV_F_TRACK_EPISODES)) {
+        ok = hipMalloc((void **)&h->ep_ret, n * sizeof(float)) == hipSuccess &&
+             hipMalloc((void **)&h->last_ret, n * sizeof(float)) == hipSuccess &&
+             hipMalloc((void **)&h->ep_len, n * sizeof(int32_t)) == hipSuccess &&
+             hipMalloc((void **)&h->last_len, n * sizeof(int32_t)) == hipSuccess;
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        free_all(h);
+        return fail(RMAV_ERR_ALLOC, "device allocation failed for %lld envs", (long long)n_envs);
+    }
+    hipError_t e = hipMemsetAsync(h->sbd, 0xFF, n * sizeof(int32_t), h->stream);  // -1 = None
+    if (e == hipSuccess) e = hipMemsetAsync(h->reset_cnt, 0, n * sizeof(uint32_t), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, sizeof(Totals), h->stream);
+    if (e == hipSuccess && (flags & RMAV_F_TRACK_EPISODES)) {
+        e = hipMemsetAsync(h->ep_ret, 0, n * sizeof(float), h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->last_ret, 0, n * sizeof(float), h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->ep_len, 0, n * sizeof(int32_t), h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->last_len, 0, n * sizeof(int32_t), h->stream);
+    }
+    if (e != hipSuccess) {
+        free_all(h);
+        return fail(RMAV_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    // the reference constructors call seed() then reset()  (quadrotor3d.py:73-74)
+    if (int rc = launch_reset(h, nullptr, RMAV_SOA)) {
+        free_all(h);
+        return rc;
+    }
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        free_all(h);
+        return fail(RMAV_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e));
+    }
+    *out = h;
+    return RMAV_OK;
+}
+
+int rmav_destroy(rmav_handle h) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    DeviceGuard guard(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    free_all(h);
+    return RMAV_OK;
+}
+
+int rmav_seed(rmav_handle h, uint64_t seed) {
+    CHECK_HANDLE(h);
+    h->seed = seed;
+    h->t = 0;
+    HIP_TRY(hipMemsetAsync(h->reset_cnt, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
+    return RMAV_OK;
+}
+
+int rmav_get_params(rmav_handle h, rmav_params *out) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    *out = h->params;
+    return RMAV_OK;
+}
+
+int rmav_set_params(rmav_handle h, const rmav_params *in) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!in) return fail(RMAV_ERR_INVALID, "in is NULL");
+    if (int rc = check_params(*in)) return rc;
+    h->params = *in;
+    return RMAV_OK;
+}
+
+int64_t rmav_num_envs(rmav_handle h) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    return h->n;
+}
+
+int rmav_sync(rmav_handle h) {
+    CHECK_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return RMAV_OK;
+}
+
+int rmav_reset(rmav_handle h, float *obs_out, int mem, int layout) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, layout)) return rc;
+    const size_t nobs = (size_t)h->n * kStateDim[h->kind];
+    if (mem == RMAV_DEVICE || !obs_out) return launch_reset(h, obs_out, layout);
+    if (int rc = ensure_scratch(h, nobs * sizeof(float))) return rc;
+    if (int rc = launch_reset(h, (float *)h->scratch, layout)) return rc;
+    return copy_out(h, (const float *)h->scratch, obs_out, nobs, RMAV_HOST);
+}
+
+int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in,
+                 float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
+                 int layout, int fused) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, layout)) return rc;
+    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (action_mode < RMAV_ACT_BUFFER || action_mode > RMAV_ACT_CONTROLLER)
+        return fail(RMAV_ERR_INVALID, "unknown action_mode %d", action_mode);
+    if (action_mode == RMAV_ACT_BUFFER && !actions_in)
+        return fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
+    const size_t n = (size_t)h->n, T = (size_t)n_steps;
+    const size_t nS = kStateDim[h->kind], nA = kActionDim[h->kind];
+    const size_t b_act = T * nA * n * sizeof(float), b_obs = T * nS * n * sizeof(float);
+    const size_t b_rew = T * n * sizeof(float), b_done = T * n;
+
+    const float *d_act_in = actions_in;
+    float *d_act_out = actions_out, *d_obs = obs_out, *d_rew = rew_out;
+    uint8_t *d_done = done_out;
+    if (mem == RMAV_HOST) {  // stage through device scratch
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        size_t off = 0, o_ain = 0, o_aout = 0, o_obs = 0, o_rew = 0, o_done = 0;
+        if (action_mode == RMAV_ACT_BUFFER) { o_ain = off; off += up(b_act); }
+        if (actions_out && action_mode != RMAV_ACT_BUFFER) { o_aout = off; off += up(b_act); }
+        if (obs_out) { o_obs = off; off += up(b_obs); }
+        if (rew_out) { o_rew = off; off += up(b_rew); }
+        if (done_out) { o_done = off; off += up(b_done); }
+        if (int rc = ensure_scratch(h, off ? off : 256)) return rc;
+        char *base = (char *)h->scratch;
+        if (action_mode == RMAV_ACT_BUFFER) {
+            HIP_TRY(hipMemcpyAsync(base + o_ain, actions_in, b_act, hipMemcpyHostToDevice, h->stream));
+            d_act_in = (const float *)(base + o_ain);
+        }
+        d_act_out = (actions_out && action_mode != RMAV_ACT_BUFFER) ? (float *)(base + o_aout) : nullptr;
+        d_obs = obs_out ? (float *)(base + o_obs) : nullptr;
+        d_rew = rew_out ? (float *)(base + o_rew) : nullptr;
+        d_done = done_out ? (uint8_t *)(base + o_done) : nullptr;
+    }
+
+    RolloutArgs a = base_args(h);
+    if (layout == RMAV_AOS) a.flags |= F_AOS;
+    if (fused) {
+        a.n_steps = n_steps;
+        a.act_in = d_act_in;
+        a.act_out = d_act_out;
+        a.obs_out = d_obs;
+        a.rew_out = d_rew;
+        a.done_out = d_done;
+        if (int rc = launch_rollout(h, action_mode, a)) return rc;
+    } else {
+        for (size_t k = 0; k < T; ++k) {
+            a.n_steps = 1;
+            a.t0 = h->t + k;
+            a.act_in = d_act_in ? d_act_in + k * nA * n : nullptr;
+            a.act_out = d_act_out ? d_act_out + k * nA * n : nullptr;
+            a.obs_out = d_obs ? d_obs + k * nS * n : nullptr;
+            a.rew_out = d_rew ? d_rew + k * n : nullptr;
+            a.done_out = d_done ? d_done + k * n : nullptr;
+            if (int rc = launch_rollout(h, action_mode, a)) return rc;
+        }
+    }
+    h->t += T;
+
+    if (mem == RMAV_HOST) {
+        if (actions_out && action_mode != RMAV_ACT_BUFFER)
+            HIP_TRY(hipMemcpyAsync(actions_out, d_act_out, b_act, hipMemcpyDeviceToHost, h->stream));
+        if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, b_obs, hipMemcpyDeviceToHost, h->stream));
+        if (rew_out) HIP_TRY(hipMemcpyAsync(rew_out, d_rew, b_rew, hipMemcpyDeviceToHost, h->stream));
+        if (done_out) HIP_TRY(hipMemcpyAsync(done_out, d_done, b_done, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (actions_out && action_mode == RMAV_ACT_BUFFER && actions_out != actions_in)
+            memcpy(actions_out, actions_in, b_act);
+    } else if (actions_out && action_mode == RMAV_ACT_BUFFER && actions_out != actions_in) {
+        HIP_TRY(hipMemcpyAsync(actions_out, actions_in, b_act, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return RMAV_OK;
+}
+
+int rmav_step(rmav_handle h, const float *actions, float *obs_out, float *rew_out,
+              uint8_t *done_out, int mem, int layout) {
+    if (!actions) return fail(RMAV_ERR_INVALID, "actions is NULL");
+    return rmav_rollout(h, 1, RMAV_ACT_BUFFER, actions, nullptr, obs_out, rew_out, done_out, mem,
+                        layout, 1);
+}
+
+int rmav_control(rmav_handle h, float *actions_out, int mem, int layout) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, layout)) return rc;
+    if (!actions_out) return fail(RMAV_ERR_INVALID, "actions_out is NULL");
+    const size_t nact = (size_t)h->n * kActionDim[h->kind];
+    if (mem == RMAV_DEVICE) return launch_control(h, actions_out, layout);
+    if (int rc = ensure_scratch(h, nact * sizeof(float))) return rc;
+    if (int rc = launch_control(h, (float *)h->scratch, layout)) return rc;
+    return copy_out(h, (const float *)h->scratch, actions_out, nact, RMAV_HOST);
+}
+
+int rmav_get_state(rmav_handle h, float *out, int mem, int layout) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, layout)) return rc;
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    const int nS = kStateDim[h->kind];
+    const size_t cnt = (size_t)h->n * nS;
+    if (layout == RMAV_SOA) return copy_out(h, (const float *)h->state, out, cnt, mem);
+    if (mem == RMAV_DEVICE) {
+        hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(kBlock), 0, h->stream, h->state, out, h->n, nS);
+        HIP_TRY(hipGetLastError());
+        return RMAV_OK;
+    }
+    if (int rc = ensure_scratch(h, cnt * sizeof(float))) return rc;
+    hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,
+                       (float *)h->scratch, h->n, nS);
+    HIP_TRY(hipGetLastError());
+    return copy_out(h, (const float *)h->scratch, out, cnt, RMAV_HOST);
+}
+
+int rmav_set_state(rmav_handle h, const float *in, int mem, int layout) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, layout)) return rc;
+    if (!in) return fail(RMAV_ERR_INVALID, "in is NULL");
+    const int nS = kStateDim[h->kind];
+    const size_t cnt = (size_t)h->n * nS;
+    if (layout == RMAV_SOA) return copy_in(h, h->state, in, cnt, mem);
+    const float *src = in;
+    if (mem == RMAV_HOST) {
+        if (int rc = ensure_scratch(h, cnt * sizeof(float))) return rc;
+        HIP_TRY(hipMemcpyAsync(h->scratch, in, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
+        src = (const float *)h->scratch;
+    }
+    hipLaunchKernelGGL(k_aos_to_soa, grid_for(h->n), dim3(kBlock), 0, h->stream, src, h->state, h->n, nS);
+    HIP_TRY(hipGetLastError());
+    if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
+    return RMAV_OK;
+}
+
+int rmav_get_sbd(rmav_handle h, int32_t *out, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    return copy_out(h, (const int32_t *)h->sbd, out, (size_t)h->n, mem);
+}
+int rmav_set_sbd(rmav_handle h, const int32_t *in, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    return copy_in(h, h->sbd, in, (size_t)h->n, mem);
+}
+int rmav_get_reset_counts(rmav_handle h, uint32_t *out, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    return copy_out(h, (const uint32_t *)h->reset_cnt, out, (size_t)h->n, mem);
+}
+int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    return copy_in(h, h->reset_cnt, in, (size_t)h->n, mem);
+}
+
+int rmav_get_step_count(rmav_handle h, uint64_t *out) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    *out = h->t;
+    return RMAV_OK;
+}
+int rmav_set_step_count(rmav_handle h, uint64_t t) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    h->t = t;
+    return RMAV_OK;
+}
+
+int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear) {
+    CHECK_HANDLE(h);
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!(h->flags & RMAV_F_TRACK_EPISODES))
+        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    Totals t;
+    HIP_TRY(hipMemcpyAsync(&t, h->totals, sizeof(t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    out->episodes = t.episodes;
+    out->return_sum = t.return_sum;
+    out->length_sum = t.length_sum;
+    if (clear) HIP_TRY(hipMemsetAsync(h->totals, 0, sizeof(Totals), h->stream));
+    return RMAV_OK;
+}
+
+int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length, float *cur_return,
+                         int32_t *cur_length, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    if (!(h->flags & RMAV_F_TRACK_EPISODES))
+        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    const size_t n = (size_t)h->n;
+    const hipMemcpyKind kind = (mem == RMAV_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (last_return) HIP_TRY(hipMemcpyAsync(last_return, h->last_ret, n * sizeof(float), kind, h->stream));
+    if (last_length) HIP_TRY(hipMemcpyAsync(last_length, h->last_len, n * sizeof(int32_t), kind, h->stream));
+    if (cur_return) HIP_TRY(hipMemcpyAsync(cur_return, h->ep_ret, n * sizeof(float), kind, h->stream));
+    if (cur_length) HIP_TRY(hipMemcpyAsync(cur_length, h->ep_len, n * sizeof(int32_t), kind, h->stream));
+    if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
+    return RMAV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,436 @@
+// rmav_math.hpp - per-env (per-lane) arithmetic of the batched quadrotor path, gfx950.
+//
+// One environment lives in the registers of one wavefront lane; everything here is lane-local
+// register math (the 3x3 / quaternion products are ~100-250 flops, far below the HBM time of the
+// 53-149 bytes an env-step moves).  Functions are __host__ __device__ so that the test-only
+// helper tests/hostmath.hip can run the SAME source on the host cores of a GPU-less box; the
+// shipped library only ever launches them inside kernels.
+//
+// Arithmetic types (R):
+//   quad2d, quad3d        : R = float.  Worst error vs the fp64 reference ~1e-7 * max(1,|y|).
+//   quad2d_sl, quad3d_sl  : R = double on fp32 storage.  The tether projection
+//                           v_l - ((v_l - v).e) e  cancels (quadrotor3d_slungload.py:128,
+//                           quadrotor2d_slungload.py:115) and fp32 misses the 1e-6 bar there;
+//                           CDNA4 runs fp64 FMA at half the fp32 rate, which this HBM-bound path
+//                           does not notice.  sin/cos stay fp32 (|d| <= 6e-8 on a unit vector).
+//   controllers           : R = double (gains of 10..50 amplify fp32 rounding past 1e-6).
+// All multiply-adds are written as explicit fma() and the library is built with
+// -ffp-contract=off, so the single-step kernel, the fused rollout kernel and the host test build
+// produce the same bits for the same inputs (up to libm's sinf/cosf/atan2).
+//
+// Reference citations are relative to gym_reinmav/envs/native/ of ethz-asl/reinmav-gym.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RMAV_HD __host__ __device__ __forceinline__
+
+namespace rmav {
+
+enum : int { QUAD2D = 0, QUAD2D_SL = 1, QUAD3D = 2, QUAD3D_SL = 3 };
+
+template <int K> struct Dims;
+template <> struct Dims<QUAD2D>    { static constexpr int NS = 5,  NA = 2; using real = float;  };
+template <> struct Dims<QUAD2D_SL> { static constexpr int NS = 9,  NA = 2; using real = double; };
+template <> struct Dims<QUAD3D>    { static constexpr int NS = 10, NA = 4; using real = float;  };
+template <> struct Dims<QUAD3D_SL> { static constexpr int NS = 16, NA = 4; using real = double; };
+
+// ---- scalar helpers -----------------------------------------------------------------------------
+RMAV_HD float  rfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+RMAV_HD double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RMAV_HD float  rsqrt_ieee(float x)  { return __builtin_sqrtf(x); }
+RMAV_HD double rsqrt_ieee(double x) { return __builtin_sqrt(x); }
+RMAV_HD float  rabs(float x)  { return __builtin_fabsf(x); }
+RMAV_HD double rabs(double x) { return __builtin_fabs(x); }
+
+// Constants of one env kind in the arithmetic type R, derived once on the host in fp64.
+template <typename R> struct ParamsT {
+    R inv_mass;      // 1/mass
+    R mass;
+    R load_mass;
+    R inv_mtot;      // 1/(mass+load_mass)
+    R dt;
+    R half_dt2;      // 0.5*dt*dt
+    R g;
+    R L;             // tether length
+    R mL;            // mass * tether length
+    R pos_limit, vel_limit;
+    R thrust_scale;
+    R kp, kv;
+    R two_over_tau;  // 3-D controller  quadrotor3d.py:173
+    R neg_inv_tau;   // 2-D controller  quadrotor2d.py:133
+    R ref_pos[3], ref_vel[3];
+    int32_t clamp_thrust;
+    int32_t _pad;
+};
+
+// ---- Philox4x32-10 (counter RNG; stream layout documented in include/rmav.h) ----------------------
+RMAV_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                           uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+RMAV_HD float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// reset(): every state component ~ U[-1,1)   (quadrotor3d.py:182-185 and the three siblings)
+template <int K>
+RMAV_HD void reset_state(uint64_t seed, uint64_t env_id, uint32_t reset_idx,
+                         float (&s)[Dims<K>::NS]) {
+    constexpr int NS = Dims<K>::NS;
+#pragma unroll
+    for (int j = 0; j * 4 < NS; ++j) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), reset_idx, (1u << 24) | (uint32_t)j,
+                      (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (j * 4 + i < NS) s[j * 4 + i] = rfma(2.0f, u01(r[i]), -1.0f);  // exact in fp32
+    }
+}
+
+template <int K>
+RMAV_HD void random_action(uint64_t seed, uint64_t env_id, uint64_t t, float lo, float hi,
+                           float (&a)[Dims<K>::NA]) {
+    uint32_t r[4];
+    philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
+                  (2u << 24) | ((uint32_t)((t >> 32) & 0xFFFFu) << 8), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int i = 0; i < Dims<K>::NA; ++i) a[i] = rfma(hi - lo, u01(r[i]), lo);
+}
+
+// ---- quaternion pieces (pyquaternion semantics the reference relies on) ------------------------
+// Quaternion._normalise(): q/|q| unless |1-|q|^2| < 1e-14 or |q| is 0 (or NaN).
+template <typename R> RMAV_HD void quat_normalise(const R (&q)[4], R (&o)[4]) {
+    const R n2 = rfma(q[0], q[0], rfma(q[1], q[1], rfma(q[2], q[2], q[3] * q[3])));
+    R s = R(1);
+    if (!(rabs(R(1) - n2) < R(1e-14))) {
+        const R n = rsqrt_ieee(n2);
+        if (n > R(0)) s = R(1) / n;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = q[i] * s;
+}
+
+// rotation_matrix . e3 for a normalised (w,x,y,z): the body z axis in world frame.
+template <typename R> RMAV_HD void quat_body_z(const R (&q)[4], R (&b)[3]) {
+    const R w = q[0], x = q[1], y = q[2], z = q[3];
+    const R t0 = rfma(x, z, w * y);
+    const R t1 = rfma(y, z, -(w * x));
+    b[0] = t0 + t0;
+    b[1] = t1 + t1;
+    b[2] = rfma(w, w, rfma(z, z, -rfma(x, x, y * y)));
+}
+
+// q' = q_raw + dt * 0.5 * qn (x) (0, w)     quadrotor3d.py:101-102  (normalised qn, raw q)
+template <typename R>
+RMAV_HD void quat_integrate(const R (&q_raw)[4], const R (&qn)[4], const R (&w)[3], R dt, R (&o)[4]) {
+    const R hw = R(0.5) * qn[0], hx = R(0.5) * qn[1], hy = R(0.5) * qn[2], hz = R(0.5) * qn[3];
+    const R e0 = -rfma(hx, w[0], rfma(hy, w[1], hz * w[2]));
+    const R e1 = rfma(hw, w[0], rfma(hy, w[2], -(hz * w[1])));
+    const R e2 = rfma(hz, w[0], rfma(hw, w[1], -(hx * w[2])));
+    const R e3 = rfma(hx, w[1], rfma(hw, w[2], -(hy * w[0])));
+    o[0] = rfma(e0, dt, q_raw[0]);
+    o[1] = rfma(e1, dt, q_raw[1]);
+    o[2] = rfma(e2, dt, q_raw[2]);
+    o[3] = rfma(e3, dt, q_raw[3]);
+}
+
+// ---- the four step() bodies ----------------------------------------------------------------------
+// Each updates the fp32 state in place and returns the distance the reward uses and `done`
+// (reward / steps_beyond_done bookkeeping is identical for all kinds and lives in the kernel).
+
+template <int K> struct Env;
+
+// Quadrotor3D.step  quadrotor3d.py:81-124
+template <> struct Env<QUAD3D> {
+    using R = float;
+    static RMAV_HD void step(float (&s)[10], const float (&a)[4], const ParamsT<R> &p, float &dist,
+                             bool &done) {
+        const R q[4] = {s[3], s[4], s[5], s[6]};
+        const R w[3] = {a[1], a[2], a[3]};
+        R qn[4], b[3], qo[4];
+        quat_normalise(q, qn);                       // :96 rotation_matrix normalises
+        quat_body_z(qn, b);
+        const R k = a[0] * p.inv_mass;               // :96 thrust/mass
+        const R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const R v = s[7 + i];
+            s[i] = rfma(acc[i], p.half_dt2, rfma(v, p.dt, s[i]));   // :98 (old velocity)
+            s[7 + i] = rfma(acc[i], p.dt, v);                        // :99
+        }
+        quat_integrate(q, qn, w, p.dt, qo);          // :101-102
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[3 + i] = qo[i];
+        const R np = rsqrt_ieee(rfma(s[0], s[0], rfma(s[1], s[1], s[2] * s[2])));
+        const R nv = rsqrt_ieee(rfma(s[7], s[7], rfma(s[8], s[8], s[9] * s[9])));
+        done = (np > p.pos_limit) || (nv > p.vel_limit);   // :106-110 (the "< -thr" clauses are dead)
+        dist = np;                                   // :113 reward = -|pos|
+    }
+};
+
+// Quadrotor3DSlungload.step  quadrotor3d_slungload.py:87-167
+template <> struct Env<QUAD3D_SL> {
+    using R = double;
+    static RMAV_HD void step(float (&s)[16], const float (&a)[4], const ParamsT<R> &p, float &dist,
+                             bool &done) {
+        R pos[3] = {s[0], s[1], s[2]};
+        const R q[4] = {s[3], s[4], s[5], s[6]};
+        R vel[3] = {s[7], s[8], s[9]};
+        R lp[3] = {s[10], s[11], s[12]};
+        R lv[3] = {s[13], s[14], s[15]};
+        const R w[3] = {a[1], a[2], a[3]};
+        const R thrust = a[0];
+        R qn[4], b[3], qo[4];
+        quat_normalise(q, qn);
+        quat_body_z(qn, b);
+        const R tv[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};     // :101
+        const R d = rsqrt_ieee(rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2])));
+        const bool taut = d >= p.L;                                           // :104
+        const R k = thrust * p.inv_mass;
+        R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};                 // :118 / :140
+        R la[3] = {R(0), R(0), -p.g};                                         // :134 slack: a_l = g
+        if (taut) {
+            const R inv_d = R(1) / d;
+            const R u[3] = {tv[0] * inv_d, tv[1] * inv_d, tv[2] * inv_d};     // :102
+            const R c = p.mL * rfma(lv[0], lv[0], rfma(lv[1], lv[1], lv[2] * lv[2]));
+            // :110 inner(u, thrust_vec - c) with the scalar c broadcast over the vector
+            const R sc = rfma(u[0], rfma(thrust, b[0], -c),
+                              rfma(u[1], rfma(thrust, b[1], -c), u[2] * rfma(thrust, b[2], -c)));
+            const R f = sc * p.inv_mtot;                                      // :111
+            la[0] = f * u[0];
+            la[1] = f * u[1];
+            la[2] = rfma(f, u[2], -p.g);
+            // :115 T = m_l * |a_l - g| * u ;  a_l - g = f*u  (exactly, before rounding)
+            const R ag[3] = {la[0], la[1], la[2] + p.g};
+            const R tn = p.load_mass * rsqrt_ieee(rfma(ag[0], ag[0], rfma(ag[1], ag[1], ag[2] * ag[2])));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);   // :118 + T/mass
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            lp[i] = rfma(la[i], p.half_dt2, rfma(lv[i], p.dt, lp[i]));        // :112 / :136
+            lv[i] = rfma(la[i], p.dt, lv[i]);                                 // :113 / :137
+            pos[i] = rfma(acc[i], p.half_dt2, rfma(vel[i], p.dt, pos[i]));    // :119 / :141
+            vel[i] = rfma(acc[i], p.dt, vel[i]);                              // :120 / :142
+        }
+        quat_integrate(q, qn, w, p.dt, qo);                                   // :122-123 / :144-145
+        if (taut) {                                                           // :126-128 projection
+            const R e[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};
+            const R inv_n = R(1) / rsqrt_ieee(rfma(e[0], e[0], rfma(e[1], e[1], e[2] * e[2])));
+            const R dir[3] = {e[0] * inv_n, e[1] * inv_n, e[2] * inv_n};
+            const R pr = rfma(lv[0] - vel[0], dir[0],
+                              rfma(lv[1] - vel[1], dir[1], (lv[2] - vel[2]) * dir[2]));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                lp[i] = rfma(dir[i], p.L, pos[i]);
+                lv[i] = rfma(-pr, dir[i], lv[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            s[i] = (float)pos[i];
+            s[7 + i] = (float)vel[i];
+            s[10 + i] = (float)lp[i];
+            s[13 + i] = (float)lv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s[3 + i] = (float)qo[i];
+        const R nlp = rsqrt_ieee(rfma(lp[0], lp[0], rfma(lp[1], lp[1], lp[2] * lp[2])));
+        const R nv = rsqrt_ieee(rfma(vel[0], vel[0], rfma(vel[1], vel[1], vel[2] * vel[2])));
+        done = (nlp > p.pos_limit) || (nv > p.vel_limit);   // :149-153 load position, quad velocity
+        dist = (float)nlp;                                  // :156 reward = -|load_pos|
+    }
+};
+
+// Quadrotor2D.step  quadrotor2d.py:74-113
+template <> struct Env<QUAD2D> {
+    using R = float;
+    static RMAV_HD void step(float (&s)[5], const float (&a)[2], const ParamsT<R> &p, float &dist,
+                             bool &done) {
+        R thrust = p.thrust_scale * a[0];                         // :75
+        if (p.clamp_thrust && thrust < R(0)) thrust = R(0);       // :76-77
+        float sn, cs;
+        sincosf(s[2], &sn, &cs);
+        // (cos(th+pi/2), sin(th+pi/2)) = (-sin th, cos th)      :88
+        const R k = thrust * p.inv_mass;
+        const R acc[2] = {k * (-sn), rfma(k, cs, -p.g)};
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const R v = s[3 + i];
+            s[i] = rfma(acc[i], p.half_dt2, rfma(v, p.dt, s[i]));  // :89 (old velocity)
+            s[3 + i] = rfma(acc[i], p.dt, v);                      // :90
+        }
+        s[2] = rfma(a[1], p.dt, s[2]);                            // :91 (no wrap)
+        const R np = rsqrt_ieee(rfma(s[0], s[0], s[1] * s[1]));
+        const R nv = rsqrt_ieee(rfma(s[3], s[3], s[4] * s[4]));
+        done = (np > p.pos_limit) || (nv > p.vel_limit);          // :95-98 under the chosen reading
+        dist = np;                                                // :102
+    }
+};
+
+// Quadrotor2DSlungload.step  quadrotor2d_slungload.py:79-154  (velocity-first updates)
+template <> struct Env<QUAD2D_SL> {
+    using R = double;
+    static RMAV_HD void step(float (&s)[9], const float (&a)[2], const ParamsT<R> &p, float &dist,
+                             bool &done) {
+        R pos[2] = {s[0], s[1]};
+        R vel[2] = {s[3], s[4]};
+        R lp[2] = {s[5], s[6]};
+        R lv[2] = {s[7], s[8]};
+        R thrust = p.thrust_scale * (R)a[0];                      // :80 (scale 1, no clamp by default)
+        if (p.clamp_thrust && thrust < R(0)) thrust = R(0);
+        float sn, cs;
+        sincosf(s[2], &sn, &cs);
+        const R dir[2] = {-(R)sn, (R)cs};
+        const R tv[2] = {lp[0] - pos[0], lp[1] - pos[1]};         // :92
+        const R d = rsqrt_ieee(rfma(tv[0], tv[0], tv[1] * tv[1]));
+        const bool taut = d >= p.L;                               // :95
+        const R k = thrust * p.inv_mass;
+        R acc[2] = {k * dir[0], rfma(k, dir[1], -p.g)};           // :107 / :128
+        R la[2] = {R(0), -p.g};                                   // :123
+        if (taut) {
+            const R inv_d = R(1) / d;
+            const R u[2] = {tv[0] * inv_d, tv[1] * inv_d};        // :93
+            const R c = p.mL * rfma(lv[0], lv[0], lv[1] * lv[1]);
+            const R sc = rfma(u[0], rfma(thrust, dir[0], -c), u[1] * rfma(thrust, dir[1], -c));  // :97
+            const R f = sc * p.inv_mtot;                          // :98
+            la[0] = f * u[0];
+            la[1] = rfma(f, u[1], -p.g);
+            const R ag[2] = {la[0], la[1] + p.g};
+            const R tn = p.load_mass * rsqrt_ieee(rfma(ag[0], ag[0], ag[1] * ag[1]));   // :102
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            lv[i] = rfma(la[i], p.dt, lv[i]);                                  // :99 / :124
+            lp[i] = rfma(la[i], p.half_dt2, rfma(lv[i], p.dt, lp[i]));         // :100 / :125 (new v)
+            vel[i] = rfma(acc[i], p.dt, vel[i]);                               // :108 / :129
+            pos[i] = rfma(acc[i], p.half_dt2, rfma(vel[i], p.dt, pos[i]));     // :109 / :130 (new v)
+        }
+        const float th = rfma(a[1], (float)p.dt, s[2]);                        // :110 / :131
+        if (taut) {                                                            // :113-115
+            const R e[2] = {lp[0] - pos[0], lp[1] - pos[1]};
+            const R inv_n = R(1) / rsqrt_ieee(rfma(e[0], e[0], e[1] * e[1]));
+            const R dr[2] = {e[0] * inv_n, e[1] * inv_n};
+            const R pr = rfma(lv[0] - vel[0], dr[0], (lv[1] - vel[1]) * dr[1]);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                lp[i] = rfma(dr[i], p.L, pos[i]);
+                lv[i] = rfma(-pr, dr[i], lv[i]);
+            }
+        }
+        s[0] = (float)pos[0]; s[1] = (float)pos[1]; s[2] = th;
+        s[3] = (float)vel[0]; s[4] = (float)vel[1];
+        s[5] = (float)lp[0];  s[6] = (float)lp[1];
+        s[7] = (float)lv[0];  s[8] = (float)lv[1];
+        const R nlp = rsqrt_ieee(rfma(lp[0], lp[0], lp[1] * lp[1]));
+        const R nlv = rsqrt_ieee(rfma(lv[0], lv[0], lv[1] * lv[1]));
+        done = (nlp > p.pos_limit) || (nlv > p.vel_limit);        // :136-140 load pos, load vel
+        dist = (float)rsqrt_ieee(rfma(pos[0], pos[0], pos[1] * pos[1]));   // :143 reward = -|quad pos|
+    }
+};
+
+// ---- geometric controllers (always fp64) -----------------------------------------------------------
+
+// Quadrotor3D.control  quadrotor3d.py:126-180  (= quadrotor3d_slungload.py:169-226)
+template <int NS>
+RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&a)[4]) {
+    using R = double;
+    R ad[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)                                   // :155-162
+        ad[i] = rfma(p.kp, (R)s[i] - p.ref_pos[i], p.kv * ((R)s[7 + i] - p.ref_vel[i]));
+    ad[2] += p.g;                                                 // - g, g = (0,0,-9.8)
+    // acc2quat :127-141 ; yc = (0,1,0)
+    const R inv_n = R(1) / rsqrt_ieee(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
+    R zb[3] = {ad[0] * inv_n, ad[1] * inv_n, ad[2] * inv_n};
+    R xb[3] = {zb[2], R(0), -zb[0]};                              // cross(yc, zb)
+    const R inv_x = R(1) / rsqrt_ieee(rfma(xb[0], xb[0], xb[2] * xb[2]));
+    xb[0] *= inv_x;
+    xb[2] *= inv_x;
+    const R yb[3] = {rfma(zb[1], xb[2], -(zb[2] * xb[1])), rfma(zb[2], xb[0], -(zb[0] * xb[2])),
+                     rfma(zb[0], xb[1], -(zb[1] * xb[0]))};       // cross(zb, xb)
+    const R inv_z = R(1) / rsqrt_ieee(rfma(zb[0], zb[0], rfma(zb[1], zb[1], zb[2] * zb[2])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) zb[i] *= inv_z;
+    // Quaternion(matrix=[xb yb zb]) : trace method on m = R^T  (m[i][j] = R[j][i])
+    // m00 = xb0, m01 = xb1, m02 = xb2 ; m10 = yb0, ... ; m20 = zb0, ...
+    const R m00 = xb[0], m01 = xb[1], m02 = xb[2];
+    const R m10 = yb[0], m11 = yb[1], m12 = yb[2];
+    const R m20 = zb[0], m21 = zb[1], m22 = zb[2];
+    R t, qd[4];
+    if (m22 < R(0)) {
+        if (m00 > m11) {
+            t = R(1) + m00 - m11 - m22;
+            qd[0] = m12 - m21; qd[1] = t; qd[2] = m01 + m10; qd[3] = m20 + m02;
+        } else {
+            t = R(1) - m00 + m11 - m22;
+            qd[0] = m20 - m02; qd[1] = m01 + m10; qd[2] = t; qd[3] = m12 + m21;
+        }
+    } else {
+        if (m00 < -m11) {
+            t = R(1) - m00 - m11 + m22;
+            qd[0] = m01 - m10; qd[1] = m20 + m02; qd[2] = m12 + m21; qd[3] = t;
+        } else {
+            t = R(1) + m00 + m11 + m22;
+            qd[0] = t; qd[1] = m12 - m21; qd[2] = m20 - m02; qd[3] = m01 - m10;
+        }
+    }
+    const R kq = R(0.5) / rsqrt_ieee(t);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) qd[i] *= kq;
+    // error_att = conj(q_raw) (x) q_des   :169   (the stored quaternion is NOT normalised here)
+    const R cw = s[3], cx = -(R)s[4], cy = -(R)s[5], cz = -(R)s[6];
+    const R qe0 = rfma(cw, qd[0], -rfma(cx, qd[1], rfma(cy, qd[2], cz * qd[3])));
+    const R qe1 = rfma(cx, qd[0], rfma(cw, qd[1], rfma(cy, qd[3], -(cz * qd[2]))));
+    const R qe2 = rfma(cy, qd[0], rfma(cz, qd[1], rfma(cw, qd[2], -(cx * qd[3]))));
+    const R qe3 = rfma(cz, qd[0], rfma(cx, qd[2], rfma(cw, qd[3], -(cy * qd[1]))));
+    // np.sign: +1 / -1 / 0, NaN propagates
+    const R sg = (qe0 > R(0)) ? R(1) : ((qe0 < R(0)) ? R(-1) : qe0);
+    const R kw = p.two_over_tau * sg;                             // :173
+    const R q[4] = {s[3], s[4], s[5], s[6]};
+    R qn[4], b[3];
+    quat_normalise(q, qn);
+    quat_body_z(qn, b);
+    a[0] = (float)rfma(ad[0], b[0], rfma(ad[1], b[1], ad[2] * b[2]));   // :176
+    a[1] = (float)(kw * qe1);
+    a[2] = (float)(kw * qe2);
+    a[3] = (float)(kw * qe3);
+}
+
+// Quadrotor2D.control  quadrotor2d.py:115-138  (= quadrotor2d_slungload.py:156-183)
+template <int NS>
+RMAV_HD void control_2d(const float (&s)[NS], const ParamsT<double> &p, float (&a)[2]) {
+    using R = double;
+    const R ax = rfma(p.kp, (R)s[0] - p.ref_pos[0], p.kv * ((R)s[3] - p.ref_vel[0]));
+    const R ay = rfma(p.kp, (R)s[1] - p.ref_pos[1], p.kv * ((R)s[4] - p.ref_vel[1])) + p.g;  // :130
+    const R th_d = atan2(ay, ax) - R(1.5707963267948966);         // :131
+    a[1] = (float)(p.neg_inv_tau * ((R)s[2] - th_d));             // :132-133
+    a[0] = (float)(p.mass * rsqrt_ieee(rfma(ax, ax, ay * ay)));   // :134
+}
+
+template <int K>
+RMAV_HD void env_control(const float (&s)[Dims<K>::NS], const ParamsT<double> &p,
+                         float (&a)[Dims<K>::NA]) {
+    if constexpr (K == QUAD3D || K == QUAD3D_SL) control_3d<Dims<K>::NS>(s, p, a);
+    else control_2d<Dims<K>::NS>(s, p, a);
+}
+
+}  // namespace rmav
