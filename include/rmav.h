@@ -129,8 +129,9 @@ int rmav_default_params(int kind, int reading_2d, rmav_params *out);
 /* ---- lifetime ------------------------------------------------------------------------------ */
 /* Creates n_envs envs of `kind` on GPU `device`; env i has global id env_id_base + i.  All envs are
  * reset once (reset index 0), like the reference constructors (quadrotor3d.py:73-74).
- * params may be NULL (defaults).  hip_stream may be NULL (the handle creates its own stream) or a
- * hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream). */
+ * params may be NULL (defaults).  hip_stream may be NULL (the handle creates its own non-blocking
+ * stream) or a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream; pass
+ * hipStreamLegacy == (void*)1 to name the legacy default stream, whose handle is 0). */
 int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t seed,
                 uint64_t env_id_base, uint32_t flags, const rmav_params *params, void *hip_stream);
 int rmav_destroy(rmav_handle h);

@@ -61,6 +61,7 @@ def lib():
         ip = C.POINTER(C.c_int)
         L.oracle_default_params.argtypes = [C.c_int, C.c_int, C.POINTER(Params)]
         L.oracle_step.argtypes = [C.c_int, C.POINTER(Params), dp, dp, dp, dp, ip, ip]
+        L.oracle_step_branch.argtypes = [C.c_int, C.POINTER(Params), dp, dp, dp, dp, ip, ip, C.c_int]
         L.oracle_control.argtypes = [C.c_int, C.POINTER(Params), dp, dp]
         L.oracle_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
         L.oracle_philox4x32_10.restype = None
@@ -91,8 +92,9 @@ def _dptr(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
-def step(kind: str, s, a, sbd: int | None = None, params: Params | None = None):
-    """One env, one step.  Returns (s_next f64[nS], reward, done, sbd_next)."""
+def step(kind: str, s, a, sbd: int | None = None, params: Params | None = None, force_taut: int = -1):
+    """One env, one step.  Returns (s_next f64[nS], reward, done, sbd_next).
+    force_taut: -1 = like the reference, 1 / 0 = force the taut / slack tether branch."""
     p = params or default_params(kind)
     s = np.ascontiguousarray(s, dtype=np.float64)
     a = np.ascontiguousarray(a, dtype=np.float64)
@@ -101,9 +103,23 @@ def step(kind: str, s, a, sbd: int | None = None, params: Params | None = None):
     r = C.c_double()
     d = C.c_int()
     sb = C.c_int(-1 if sbd is None else int(sbd))
-    rc = lib().oracle_step(KINDS[kind], C.byref(p), _dptr(s), _dptr(a), _dptr(o), C.byref(r), C.byref(d), C.byref(sb))
+    rc = lib().oracle_step_branch(KINDS[kind], C.byref(p), _dptr(s), _dptr(a), _dptr(o), C.byref(r), C.byref(d),
+                                  C.byref(sb), int(force_taut))
     assert rc == 0
     return o, r.value, bool(d.value), (None if sb.value < 0 else sb.value)
+
+
+TETHER = {"quad2d_sl": (slice(0, 2), slice(5, 7)), "quad3d_sl": (slice(0, 3), slice(10, 13))}
+
+
+def tether_slack(kind: str, s, params: Params | None = None) -> np.ndarray:
+    """|load_pos - pos| - L per env (0-d for one env); NaN for kinds without a tether."""
+    s = np.asarray(s, dtype=np.float64)
+    if kind not in TETHER:
+        return np.full(s.shape[:-1], np.nan)
+    p = params or default_params(kind)
+    ps, ls = TETHER[kind]
+    return np.linalg.norm(s[..., ls] - s[..., ps], axis=-1) - p.tether_length
 
 
 def control(kind: str, s, params: Params | None = None) -> np.ndarray:

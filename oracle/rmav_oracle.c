@@ -202,7 +202,7 @@ static void step_quad3d(const oracle_params *p, const double *s, const double *a
 
 /* ---- Quadrotor3DSlungload.step  quadrotor3d_slungload.py:87-167 ------------------------------- */
 static void step_quad3d_sl(const oracle_params *p, const double *s, const double *a, double *o,
-                           double *reward, int *done, int *sbd) {
+                           double *reward, int *done, int *sbd, int force_taut) {
     const double dt = p->dt, L = p->tether_length;
     double thrust = a[0];
     const double *w = a + 1;
@@ -218,7 +218,7 @@ static void step_quad3d_sl(const oracle_params *p, const double *s, const double
     for (int i = 0; i < 3; ++i) u[i] = tv[i] / d;                /* :102 */
     quat_normalise(att, qn);
     quat_body_z(qn, b3);
-    if (d >= L) {                                                /* :104 taut */
+    if (force_taut < 0 ? (d >= L) : force_taut) {                /* :104 taut */
         double thr_vec[3], tmp[3], T[3], ldir[3], dlp[3], dv[3];
         for (int i = 0; i < 3; ++i) thr_vec[i] = thrust * b3[i]; /* :109 */
         double c = p->mass * L * inner(lv, lv, 3);
@@ -287,7 +287,7 @@ static void step_quad2d(const oracle_params *p, const double *s, const double *a
 
 /* ---- Quadrotor2DSlungload.step  quadrotor2d_slungload.py:79-154 (velocity-first updates) ------- */
 static void step_quad2d_sl(const oracle_params *p, const double *s, const double *a, double *o,
-                           double *reward, int *done, int *sbd) {
+                           double *reward, int *done, int *sbd, int force_taut) {
     const double dt = p->dt, L = p->tether_length;
     double thrust = p->thrust_scale * a[0];               /* :80 (scale 1: no x10, no clamp) */
     if (p->clamp_thrust && thrust < 0.0) thrust = 0.0;
@@ -300,7 +300,7 @@ static void step_quad2d_sl(const oracle_params *p, const double *s, const double
     double d = norm2(tv, 2);
     for (int i = 0; i < 2; ++i) u[i] = tv[i] / d;         /* :93 */
     double dir[2] = {cos(att + M_PI / 2), sin(att + M_PI / 2)};
-    if (d >= L) {                                         /* :95 taut */
+    if (force_taut < 0 ? (d >= L) : force_taut) {         /* :95 taut */
         double thr_vec[2], tmp[2], T[2], ldir[2], dlp[2], dv[2];
         for (int i = 0; i < 2; ++i) thr_vec[i] = thrust * dir[i];                          /* :96 */
         double c = p->mass * L * inner(lv, lv, 2);
@@ -341,15 +341,20 @@ static void step_quad2d_sl(const oracle_params *p, const double *s, const double
     *reward = reward_machine(*done, norm2(pos, 2), sbd); /* :142-152 reward -|quad pos| */
 }
 
-int oracle_step(int kind, const oracle_params *p, const double *s, const double *a, double *s_out,
-                double *reward, int *done, int *sbd) {
+int oracle_step_branch(int kind, const oracle_params *p, const double *s, const double *a,
+                       double *s_out, double *reward, int *done, int *sbd, int force_taut) {
     switch (kind) {
     case ORACLE_QUAD2D: step_quad2d(p, s, a, s_out, reward, done, sbd); return 0;
-    case ORACLE_QUAD2D_SL: step_quad2d_sl(p, s, a, s_out, reward, done, sbd); return 0;
+    case ORACLE_QUAD2D_SL: step_quad2d_sl(p, s, a, s_out, reward, done, sbd, force_taut); return 0;
     case ORACLE_QUAD3D: step_quad3d(p, s, a, s_out, reward, done, sbd); return 0;
-    case ORACLE_QUAD3D_SL: step_quad3d_sl(p, s, a, s_out, reward, done, sbd); return 0;
+    case ORACLE_QUAD3D_SL: step_quad3d_sl(p, s, a, s_out, reward, done, sbd, force_taut); return 0;
     }
     return -1;
+}
+
+int oracle_step(int kind, const oracle_params *p, const double *s, const double *a, double *s_out,
+                double *reward, int *done, int *sbd) {
+    return oracle_step_branch(kind, p, s, a, s_out, reward, done, sbd, -1);
 }
 
 /* ---- Quadrotor3D.control  quadrotor3d.py:126-180 (= quadrotor3d_slungload.py:169-226) ---------- */

@@ -54,6 +54,13 @@ int oracle_default_params(int kind, int reading_2d, oracle_params *p);
 int oracle_step(int kind, const oracle_params *p, const double *s, const double *a, double *s_out,
                 double *reward, int *done, int *sbd);
 
+/* Same with the tether branch of the slung-load kinds forced: force_taut = 1 (taut), 0 (slack),
+ * -1 (decide by |tether| >= L like the reference).  The kinematic projection leaves |tether| = L up
+ * to rounding, so in closed loop the next step's branch is decided by the last bit of a norm (and,
+ * in the reference, by whether NumPy's BLAS dot uses FMA); tests accept either branch there. */
+int oracle_step_branch(int kind, const oracle_params *p, const double *s, const double *a,
+                       double *s_out, double *reward, int *done, int *sbd, int force_taut);
+
 /* Geometric controller of the reference's test loop: state -> action. */
 int oracle_control(int kind, const oracle_params *p, const double *s, double *a_out);
 

@@ -1,0 +1,130 @@
+"""ctypes binding of ``librmav.so`` (the C ABI declared in ``include/rmav.h``).
+
+The library is the only implementation: if it is missing or no GPU is visible, importing succeeds
+(so that host-only logic stays testable) but creating an env raises - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librmav.so")
+
+# enums of include/rmav.h
+QUAD2D, QUAD2D_SL, QUAD3D, QUAD3D_SL = 0, 1, 2, 3
+KIND_NAMES = {QUAD2D: "quad2d", QUAD2D_SL: "quad2d_sl", QUAD3D: "quad3d", QUAD3D_SL: "quad3d_sl"}
+KIND_BY_NAME = {v: k for k, v in KIND_NAMES.items()}
+STATE_DIM = {QUAD2D: 5, QUAD2D_SL: 9, QUAD3D: 10, QUAD3D_SL: 16}
+ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4}
+HOST, DEVICE = 0, 1
+SOA, AOS = 0, 1
+ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER = 0, 1, 2
+F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
+
+
+class RmavError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"librmav error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """``rmav_params``."""
+
+    _fields_ = [
+        ("mass", C.c_double),
+        ("load_mass", C.c_double),
+        ("dt", C.c_double),
+        ("g", C.c_double),
+        ("tether_length", C.c_double),
+        ("pos_limit", C.c_double),
+        ("vel_limit", C.c_double),
+        ("thrust_scale", C.c_double),
+        ("clamp_thrust", C.c_int32),
+        ("_pad", C.c_int32),
+        ("ref_pos", C.c_double * 3),
+        ("ref_vel", C.c_double * 3),
+        ("kp", C.c_double),
+        ("kv", C.c_double),
+        ("tau", C.c_double),
+        ("act_lo", C.c_double),
+        ("act_hi", C.c_double),
+    ]
+
+
+class EpTotals(C.Structure):
+    _fields_ = [("episodes", C.c_uint64), ("return_sum", C.c_double), ("length_sum", C.c_uint64)]
+
+
+# name -> (restype, argtypes); also the list the symbol-export test walks.
+_vp, _fp, _u8p = C.c_void_p, C.c_void_p, C.c_void_p  # raw addresses: host arrays or device pointers
+PROTOTYPES = {
+    "rmav_version": (C.c_int, []),
+    "rmav_last_error": (C.c_char_p, []),
+    "rmav_device_count": (C.c_int, []),
+    "rmav_state_dim": (C.c_int, [C.c_int]),
+    "rmav_action_dim": (C.c_int, [C.c_int]),
+    "rmav_algorithmic_bytes": (C.c_int, [C.c_int]),
+    "rmav_default_params": (C.c_int, [C.c_int, C.c_int, C.POINTER(Params)]),
+    "rmav_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_uint64, C.c_uint64,
+                              C.c_uint32, C.POINTER(Params), C.c_void_p]),
+    "rmav_destroy": (C.c_int, [C.c_void_p]),
+    "rmav_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rmav_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "rmav_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "rmav_num_envs": (C.c_int64, [C.c_void_p]),
+    "rmav_sync": (C.c_int, [C.c_void_p]),
+    "rmav_reset": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "rmav_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _u8p, C.c_int, C.c_int]),
+    "rmav_control": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "rmav_rollout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int, C.c_int,
+                               C.c_int]),
+    "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "rmav_set_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "rmav_get_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_set_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_get_reset_counts": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_set_reset_counts": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_get_step_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rmav_set_step_count": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "rmav_episode_totals": (C.c_int, [C.c_void_p, C.POINTER(EpTotals), C.c_int]),
+    "rmav_episode_buffers": (C.c_int, [C.c_void_p, _fp, _vp, _fp, _vp, C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librmav.so (once).  Raises if it has not been built - never falls back to anything."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RmavError(ERR_NO_DEVICE, f"{LIB_PATH} not found: build it with `make -C reinmav-gym_amd` "
+                                           "(or __graft_entry__.build()); there is no CPU fallback")
+        try:  # share torch's HIP runtime when torch is in the process (same SONAME libamdhip64.so.7)
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for pure-ctypes use
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.rmav_version() != 100:
+            raise RmavError(ERR_INVALID, "librmav.so version mismatch; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise RmavError(rc, lib().rmav_last_error().decode("utf-8", "replace"))
+    return rc
+
+
+def default_params(kind: int, reading_2d: str | None = None) -> Params:
+    p = Params()
+    check(lib().rmav_default_params(kind, ord(reading_2d) if reading_2d else 0, C.byref(p)))
+    return p

@@ -1,0 +1,238 @@
+"""``BatchedQuadrotor``: N independent envs of one kind resident on one MI355X, behind ``librmav.so``.
+
+Thin, allocation-aware plumbing over the C ABI:
+
+* NumPy arrays in -> ``RMAV_HOST`` calls (library stages + synchronises), NumPy arrays out.
+* torch CUDA tensors in -> ``RMAV_DEVICE`` calls: pointers are handed over as-is, work is enqueued on
+  the torch stream the env was created on, nothing synchronises, tensors come back.
+
+Layouts: ``"aos"`` = ``[N, dim]`` (what gym / a policy hands over), ``"soa"`` = ``[dim, N]`` (native,
+coalesced).  Trajectories are time-major: ``[T, N, dim]`` / ``[T, dim, N]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _abi as A
+
+try:  # torch is plumbing (device memory / streams); the host-array API works without it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+_MODES = {"buffer": A.ACT_BUFFER, "random": A.ACT_RANDOM, "controller": A.ACT_CONTROLLER}
+
+
+def _is_tensor(x) -> bool:
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _layout(layout: str) -> int:
+    if layout not in ("aos", "soa"):
+        raise ValueError("layout must be 'aos' or 'soa'")
+    return A.AOS if layout == "aos" else A.SOA
+
+
+class BatchedQuadrotor:
+    """N envs of ``kind`` ('quad2d' | 'quad2d_sl' | 'quad3d' | 'quad3d_sl') on GPU ``device``."""
+
+    def __init__(self, kind, num_envs: int, device: int = 0, seed: int = 0, env_id_base: int = 0,
+                 auto_reset: bool = True, track_episodes: bool = True, params: Optional[A.Params] = None,
+                 reading_2d: Optional[str] = None, use_torch_stream: bool = True):
+        self.kind = A.KIND_BY_NAME[kind] if isinstance(kind, str) else int(kind)
+        self.kind_name = A.KIND_NAMES[self.kind]
+        self.num_envs = int(num_envs)
+        self.nS, self.nA = A.STATE_DIM[self.kind], A.ACTION_DIM[self.kind]
+        self.device = int(device)
+        self.auto_reset, self.track_episodes = bool(auto_reset), bool(track_episodes)
+        self._lib = A.lib()
+        p = params if params is not None else A.default_params(self.kind, reading_2d)
+        stream = None
+        self._tstream = None
+        if use_torch_stream and torch is not None and torch.cuda.is_available():
+            self._tstream = torch.cuda.current_stream(self.device)
+            # torch's default stream is the legacy NULL stream (handle 0); NULL means "create your own"
+            # in rmav_create, so name it explicitly: hipStreamLegacy == (hipStream_t)1.
+            stream = C.c_void_p(self._tstream.cuda_stream or 1)
+        flags = (A.F_AUTO_RESET if auto_reset else 0) | (A.F_TRACK_EPISODES if track_episodes else 0)
+        h = C.c_void_p()
+        A.check(self._lib.rmav_create(C.byref(h), self.kind, self.num_envs, self.device, seed & (2**64 - 1),
+                                      env_id_base, flags, C.byref(p), stream))
+        self._h = h
+
+    # ---- lifetime ------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.rmav_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def seed(self, seed: int):
+        A.check(self._lib.rmav_seed(self._h, int(seed) & (2**64 - 1)))
+
+    def sync(self):
+        A.check(self._lib.rmav_sync(self._h))
+
+    @property
+    def params(self) -> A.Params:
+        p = A.Params()
+        A.check(self._lib.rmav_get_params(self._h, C.byref(p)))
+        return p
+
+    @params.setter
+    def params(self, p: A.Params):
+        A.check(self._lib.rmav_set_params(self._h, C.byref(p)))
+
+    @property
+    def step_count(self) -> int:
+        t = C.c_uint64()
+        A.check(self._lib.rmav_get_step_count(self._h, C.byref(t)))
+        return t.value
+
+    @step_count.setter
+    def step_count(self, t: int):
+        A.check(self._lib.rmav_set_step_count(self._h, int(t)))
+
+    # ---- buffer helpers --------------------------------------------------------------------------------
+    def _shape(self, dim: int, layout: str, T: Optional[int] = None):
+        core = (self.num_envs, dim) if layout == "aos" else (dim, self.num_envs)
+        return core if T is None else (T,) + core
+
+    def _new(self, shape, dtype, like_tensor: bool):
+        if like_tensor:
+            tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}[dtype]
+            return torch.empty(shape, dtype=tdt, device=f"cuda:{self.device}")
+        return np.empty(shape, dtype=dtype)
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return None
+        if _is_tensor(x):
+            assert x.is_contiguous(), "device buffers must be contiguous"
+            return C.c_void_p(x.data_ptr())
+        assert x.flags.c_contiguous
+        return C.c_void_p(x.ctypes.data)
+
+    def _in(self, x, shape, dtype=np.float32):
+        """Validate / convert a caller array; returns (array, mem)."""
+        if _is_tensor(x):
+            if not x.is_cuda or x.device.index != self.device:
+                raise ValueError(f"tensor must live on cuda:{self.device}")
+            tdt = {np.float32: torch.float32, np.int32: torch.int32, np.uint32: torch.int32}[dtype]
+            if x.dtype != tdt:
+                x = x.to(tdt)
+            if tuple(x.shape) != tuple(shape):
+                raise ValueError(f"expected shape {tuple(shape)}, got {tuple(x.shape)}")
+            return x.contiguous(), A.DEVICE
+        x = np.ascontiguousarray(x, dtype=dtype)
+        if x.shape != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {x.shape}")
+        return x, A.HOST
+
+    # ---- the hot path ----------------------------------------------------------------------------------
+    def reset(self, layout: str = "aos", device_out: bool = False):
+        obs = self._new(self._shape(self.nS, layout), np.float32, device_out)
+        A.check(self._lib.rmav_reset(self._h, self._ptr(obs), A.DEVICE if device_out else A.HOST, _layout(layout)))
+        return obs
+
+    def step(self, actions, layout: str = "aos", out=None):
+        """actions [N,nA] ('aos') or [nA,N] ('soa') -> (obs, reward f32[N], done u8/bool[N]).
+
+        ``out`` may carry preallocated (obs, rew, done) buffers of the same family as ``actions``."""
+        a, mem = self._in(actions, self._shape(self.nA, layout))
+        dev = mem == A.DEVICE
+        if out is None:
+            obs = self._new(self._shape(self.nS, layout), np.float32, dev)
+            rew = self._new((self.num_envs,), np.float32, dev)
+            done = self._new((self.num_envs,), np.uint8, dev)
+        else:
+            obs, rew, done = out
+        A.check(self._lib.rmav_step(self._h, self._ptr(a), self._ptr(obs), self._ptr(rew), self._ptr(done), mem,
+                                    _layout(layout)))
+        if not dev and out is None:
+            done = done.astype(bool)
+        return obs, rew, done
+
+    def control(self, layout: str = "aos", device_out: bool = False):
+        act = self._new(self._shape(self.nA, layout), np.float32, device_out)
+        A.check(self._lib.rmav_control(self._h, self._ptr(act), A.DEVICE if device_out else A.HOST, _layout(layout)))
+        return act
+
+    def rollout(self, n_steps: int, mode: str = "random", actions=None, layout: str = "soa", fused: bool = True,
+                want=("obs", "rew", "done"), device_out: bool = False, out: Optional[dict] = None) -> dict:
+        """Run ``n_steps`` steps of every env.  Returns a dict of the requested trajectories
+        (subset of 'actions', 'obs', 'rew', 'done').  ``out`` may carry preallocated buffers."""
+        T = int(n_steps)
+        m = _MODES[mode]
+        a_in, mem = None, (A.DEVICE if device_out else A.HOST)
+        if m == A.ACT_BUFFER:
+            a_in, mem = self._in(actions, self._shape(self.nA, layout, T))
+        dev = mem == A.DEVICE
+        res = dict(out) if out else {}
+        if "actions" in want and m != A.ACT_BUFFER and "actions" not in res:
+            res["actions"] = self._new(self._shape(self.nA, layout, T), np.float32, dev)
+        if "obs" in want and "obs" not in res:
+            res["obs"] = self._new(self._shape(self.nS, layout, T), np.float32, dev)
+        if "rew" in want and "rew" not in res:
+            res["rew"] = self._new((T, self.num_envs), np.float32, dev)
+        if "done" in want and "done" not in res:
+            res["done"] = self._new((T, self.num_envs), np.uint8, dev)
+        A.check(self._lib.rmav_rollout(self._h, T, m, self._ptr(a_in), self._ptr(res.get("actions")) if m != A.ACT_BUFFER else None,
+                                       self._ptr(res.get("obs")), self._ptr(res.get("rew")), self._ptr(res.get("done")),
+                                       mem, _layout(layout), 1 if fused else 0))
+        if m == A.ACT_BUFFER and "actions" in want:
+            res["actions"] = a_in
+        return res
+
+    # ---- state access ----------------------------------------------------------------------------------
+    def get_state(self, layout: str = "aos", device_out: bool = False):
+        s = self._new(self._shape(self.nS, layout), np.float32, device_out)
+        A.check(self._lib.rmav_get_state(self._h, self._ptr(s), A.DEVICE if device_out else A.HOST, _layout(layout)))
+        return s
+
+    def set_state(self, s, layout: str = "aos"):
+        s, mem = self._in(s, self._shape(self.nS, layout))
+        A.check(self._lib.rmav_set_state(self._h, self._ptr(s), mem, _layout(layout)))
+
+    def get_sbd(self) -> np.ndarray:
+        out = np.empty(self.num_envs, dtype=np.int32)
+        A.check(self._lib.rmav_get_sbd(self._h, self._ptr(out), A.HOST))
+        return out
+
+    def set_sbd(self, sbd):
+        sbd = np.ascontiguousarray(sbd, dtype=np.int32)
+        assert sbd.shape == (self.num_envs,)
+        A.check(self._lib.rmav_set_sbd(self._h, self._ptr(sbd), A.HOST))
+
+    def get_reset_counts(self) -> np.ndarray:
+        out = np.empty(self.num_envs, dtype=np.uint32)
+        A.check(self._lib.rmav_get_reset_counts(self._h, self._ptr(out), A.HOST))
+        return out
+
+    def set_reset_counts(self, rc):
+        rc = np.ascontiguousarray(rc, dtype=np.uint32)
+        assert rc.shape == (self.num_envs,)
+        A.check(self._lib.rmav_set_reset_counts(self._h, self._ptr(rc), A.HOST))
+
+    # ---- episode statistics ------------------------------------------------------------------------------
+    def episode_totals(self, clear: bool = False) -> dict:
+        t = A.EpTotals()
+        A.check(self._lib.rmav_episode_totals(self._h, C.byref(t), 1 if clear else 0))
+        return {"episodes": int(t.episodes), "return_sum": float(t.return_sum), "length_sum": int(t.length_sum)}
+
+    def episode_buffers(self, device_out: bool = False) -> dict:
+        n = (self.num_envs,)
+        lr, ll = self._new(n, np.float32, device_out), self._new(n, np.int32, device_out)
+        cr, cl = self._new(n, np.float32, device_out), self._new(n, np.int32, device_out)
+        A.check(self._lib.rmav_episode_buffers(self._h, self._ptr(lr), self._ptr(ll), self._ptr(cr), self._ptr(cl),
+                                               A.DEVICE if device_out else A.HOST))
+        return {"last_return": lr, "last_length": ll, "cur_return": cr, "cur_length": cl}

@@ -1,0 +1,78 @@
+"""Sharding of the env batch over the GPUs of one node, and the one collective the path has.
+
+Envs are independent, so the data path needs no communication: rank ``r`` of ``R`` owns a contiguous
+range of GLOBAL env ids and keys its RNG by the global id, which makes results independent of ``R``.
+The only exchange is one all-gather of per-env episode statistics per rollout (RCCL over xGMI when
+the tensors are on GPUs and the process group backend is ``nccl``; ``gloo`` on CPU tensors in tests).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+try:
+    import torch
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    torch = None
+    dist = None
+
+
+def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
+    """(first global env id, count) of ``rank``; the remainder goes to the lowest ranks."""
+    if world <= 0 or not (0 <= rank < world) or n_total < 0:
+        raise ValueError("need 0 <= rank < world and n_total >= 0")
+    base, rem = divmod(int(n_total), int(world))
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def make_sharded(kind, n_total: int, rank: int, world: int, device: Optional[int] = None, seed: int = 0, **kw):
+    """This rank's ``BatchedQuadrotor`` shard of an ``n_total``-env batch (same ``seed`` on every rank)."""
+    from .core import BatchedQuadrotor
+
+    start, count = shard_range(n_total, rank, world)
+    if count == 0:
+        raise ValueError("empty shard: fewer envs than ranks")
+    return BatchedQuadrotor(kind, count, device=rank if device is None else device, seed=seed, env_id_base=start, **kw)
+
+
+def all_gather_episode_stats(last_return, last_length, n_total: int, group=None):
+    """All-gather per-env (return, length) of the most recently finished episodes.
+
+    ``last_return`` f32[count], ``last_length`` i32[count] are this rank's shard (torch tensors, on
+    the GPU for the nccl backend).  Returns (returns f32[n_total], lengths i32[n_total]) in global env
+    order on every rank.  Shards may differ by one env, so each rank pads to the largest shard."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    _, count = shard_range(n_total, rank, world)
+    assert last_return.shape[0] == count and last_length.shape[0] == count
+    cmax = -(-n_total // world)
+    pad = cmax - count
+    # one message: returns and lengths packed into a single int32 buffer (bit-cast), 8*cmax bytes/rank
+    send = torch.empty(2 * cmax, dtype=torch.int32, device=last_return.device)
+    send[:count] = last_return.contiguous().view(torch.int32)
+    send[cmax:cmax + count] = last_length
+    if pad:
+        send[count:cmax] = 0
+        send[cmax + count:] = 0
+    recv = torch.empty(world * 2 * cmax, dtype=torch.int32, device=last_return.device)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    recv = recv.view(world, 2, cmax)
+    rets, lens = [], []
+    for r in range(world):
+        _, c = shard_range(n_total, r, world)
+        rets.append(recv[r, 0, :c].view(torch.float32))
+        lens.append(recv[r, 1, :c])
+    return torch.cat(rets), torch.cat(lens)
+
+
+def all_reduce_totals(totals: dict, device=None, group=None) -> dict:
+    """Sum {'episodes','return_sum','length_sum'} over ranks (one 3-element all-reduce)."""
+    t = torch.tensor([float(totals["episodes"]), float(totals["return_sum"]), float(totals["length_sum"])],
+                     dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    e, r, l = t.tolist()
+    return {"episodes": int(round(e)), "return_sum": r, "length_sum": int(round(l))}

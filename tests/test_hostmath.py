@@ -1,0 +1,87 @@
+"""The kernels' per-lane arithmetic (csrc/rmav_math.hpp, compiled for the host by the test-only helper
+tests/hostmath) against the fp64 oracle and the reference's golden vectors: the fp32 / mixed-precision
+design meets the 1e-6 * max(1,|y|) bar before any GPU run."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from util import CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, random_cases, scaled_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FP = C.POINTER(C.c_float)
+
+
+@pytest.fixture(scope="module")
+def hm(built):
+    return C.CDLL(os.path.join(ROOT, "tests", "hostmath", "_build", "libhostmath.so"))
+
+
+def _step(hm, kind, s, a, reading=None):
+    from gym_reinmav_amd import _abi as A
+
+    k = A.KIND_BY_NAME[kind]
+    p = A.default_params(k, reading)
+    s2 = np.ascontiguousarray(s, dtype=np.float32).copy()
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    n = len(s2)
+    dist = np.zeros(n, np.float32)
+    done = np.zeros(n, np.int32)
+    assert hm.hm_step(k, C.byref(p), C.c_int64(n), s2.ctypes.data_as(FP), a.ctypes.data_as(FP),
+                      dist.ctypes.data_as(FP), done.ctypes.data_as(C.POINTER(C.c_int32))) == 0
+    return s2, dist, done.astype(bool)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_step_arithmetic_vs_golden(hm, kind, golden):
+    g = golden[kind]
+    s2, dist, done = _step(hm, kind, g["step_s"], g["step_a"])
+    assert scaled_err(s2, g["step_s2"]).max() <= TOL
+    ok = near_threshold(kind, g["step_s2"])
+    assert np.array_equal(done | ok, g["step_d"] | ok)
+    alive = ~g["step_d"] & ~done
+    assert scaled_err(-dist[alive], g["step_r"][alive]).max() <= TOL
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_step_arithmetic_vs_oracle_random(hm, kind):
+    s, a = random_cases(kind, 20000, seed=21)
+    s2, dist, done = _step(hm, kind, s, a)
+    o2, r, d, _ = O.batch_step(kind, s.astype(np.float64), a.astype(np.float64))
+    assert scaled_err(s2, o2).max() <= TOL
+    ok = near_threshold(kind, o2)
+    assert np.array_equal(done | ok, d | ok)
+    alive = ~d & ~done
+    assert scaled_err(-dist[alive], r[alive]).max() <= TOL
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_control_arithmetic(hm, kind, golden):
+    from gym_reinmav_amd import _abi as A
+
+    k = A.KIND_BY_NAME[kind]
+    p = A.default_params(k)
+    g = golden[kind]
+    cs = g["ctrl_s"].astype(np.float32)
+    ca = np.zeros((len(cs), NA[kind]), np.float32)
+    assert hm.hm_control(k, C.byref(p), C.c_int64(len(cs)), cs.ctypes.data_as(FP), ca.ctypes.data_as(FP)) == 0
+    assert scaled_err(ca, g["ctrl_a"]).max() <= CTRL_TOL
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_rng_streams_bit_exact(hm, kind):
+    from gym_reinmav_amd import _abi as A
+
+    k = A.KIND_BY_NAME[kind]
+    for env in (0, 1, 65535, 2**40 + 3):
+        for idx in (0, 1, 77):
+            s = np.zeros(NS[kind], np.float32)
+            hm.hm_reset_state(k, C.c_uint64(9), C.c_uint64(env), C.c_uint32(idx), s.ctypes.data_as(FP))
+            assert np.array_equal(s, O.reset_state(kind, 9, env, idx))
+        for t in (0, 5, 2**33 + 1):
+            a = np.zeros(NA[kind], np.float32)
+            hm.hm_random_action(k, C.c_uint64(9), C.c_uint64(env), C.c_uint64(t), C.c_float(-10), C.c_float(10),
+                                a.ctypes.data_as(FP))
+            assert np.array_equal(a, O.random_action(kind, 9, env, t, -10.0, 10.0))
