@@ -93,6 +93,8 @@ int check_params(const rmav_params &q) {
     return RMAV_OK;
 }
 
+inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
+
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 int ensure_scratch(rmav_handle h, size_t bytes) {
@@ -355,7 +357,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     bool ok = hipMalloc((void **)&h->state, n * nS * sizeof(float)) == hipSuccess &&
               hipMalloc((void **)&h->sbd, n * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&h->reset_cnt, n * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&h->totals, sizeof(Totals)) == hipSuccess;
+              hipMalloc((void **)&h->totals, n_waves(n_envs) * sizeof(Totals)) == hipSuccess;
     if (ok && (flags & RMAV_F_TRACK_EPISODES)) {
         ok = hipMalloc((void **)&h->ep_ret, n * sizeof(float)) == hipSuccess &&
              hipMalloc((void **)&h->last_ret, n * sizeof(float)) == hipSuccess &&
@@ -369,7 +371,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     }
     hipError_t e = hipMemsetAsync(h->sbd, 0xFF, n * sizeof(int32_t), h->stream);  // -1 = None
     if (e == hipSuccess) e = hipMemsetAsync(h->reset_cnt, 0, n * sizeof(uint32_t), h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, sizeof(Totals), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, n_waves(n_envs) * sizeof(Totals), h->stream);
     if (e == hipSuccess && (flags & RMAV_F_TRACK_EPISODES)) {
         e = hipMemsetAsync(h->ep_ret, 0, n * sizeof(float), h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->last_ret, 0, n * sizeof(float), h->stream);
@@ -617,13 +619,25 @@ int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear) {
     if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
         return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
-    Totals t;
-    HIP_TRY(hipMemcpyAsync(&t, h->totals, sizeof(t), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    out->episodes = t.episodes;
-    out->return_sum = t.return_sum;
-    out->length_sum = t.length_sum;
-    if (clear) HIP_TRY(hipMemsetAsync(h->totals, 0, sizeof(Totals), h->stream));
+    const size_t nw = n_waves(h->n);
+    Totals *host = new (std::nothrow) Totals[nw];
+    if (!host) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    hipError_t e = hipMemcpyAsync(host, h->totals, nw * sizeof(Totals), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        delete[] host;
+        return fail(RMAV_ERR_HIP, "reading episode totals failed: %s", hipGetErrorString(e));
+    }
+    out->episodes = 0;
+    out->return_sum = 0.0;
+    out->length_sum = 0;
+    for (size_t i = 0; i < nw; ++i) {
+        out->episodes += host[i].episodes;
+        out->return_sum += host[i].return_sum;
+        out->length_sum += host[i].length_sum;
+    }
+    delete[] host;
+    if (clear) HIP_TRY(hipMemsetAsync(h->totals, 0, nw * sizeof(Totals), h->stream));
     return RMAV_OK;
 }
 

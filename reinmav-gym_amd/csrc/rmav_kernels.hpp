@@ -7,6 +7,7 @@
 //   sbd        i32 [N]       steps_beyond_done (-1 = None); touched only by lanes whose env is done
 //   reset_cnt  u32 [N]       resets drawn so far (RNG counter); touched only on reset
 //   ep_ret/ep_len, last_ret/last_len   optional Monitor-style episode accumulators
+//   totals     {u64,f64,u64} [ceil(N/64)]  per-wavefront partial sums of finished episodes
 // Caller buffers: actions [T][nA][N] | [T][N][nA], obs [T][nS][N] | [T][N][nS], rew f32 [T][N],
 // done u8 [T][N].
 //
@@ -84,6 +85,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
             er = a.ep_ret[i];
             el = a.ep_len[i];
         }
+        // steps_beyond_done and the reset counter ride in registers for the whole launch: loading them
+        // on demand (only lanes that terminate need them) would put one or two dependent HBM round
+        // trips into every step of every wavefront that has a finishing lane (~57 % of them at the
+        // 1.3 %/step termination rate of random actions).
+        int32_t sb = a.sbd[i];
+        uint32_t rc = a.reset_cnt[i];
+        const int32_t sb0 = sb;
+        const uint32_t rc0 = rc;
         const uint64_t env_id = a.env_base + (uint64_t)i;
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
@@ -122,9 +131,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
             // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
             float r = -dist;
             if (done) {
-                int32_t sb = a.sbd[i];
-                if (sb < 0) { r = 1.0f; sb = 0; } else { r = 0.0f; sb += 1; }
-                a.sbd[i] = sb;
+                r = (sb < 0) ? 1.0f : 0.0f;
+                sb = (sb < 0) ? 0 : sb + 1;
             }
             if (track) {
                 er += r;
@@ -140,9 +148,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                 }
             }
             if (done && auto_reset) {
-                const uint32_t rc = a.reset_cnt[i];
                 reset_state<K>(a.seed, env_id, rc, s);
-                a.reset_cnt[i] = rc + 1;
+                rc += 1;
             }
             if (a.obs_out) {
                 if (aos) {
@@ -165,16 +172,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
             a.ep_ret[i] = er;
             a.ep_len[i] = el;
         }
+        if (sb != sb0) a.sbd[i] = sb;
+        if (rc != rc0) a.reset_cnt[i] = rc;
     }
 
-    if (track) {  // one atomic triple per wavefront that finished at least one episode
+    if (track) {
+        // Episode totals: each wavefront owns one slot of a [ceil(N/64)] partials array and adds to it
+        // with plain loads/stores (launches on a handle are stream-ordered, so nobody else touches the
+        // slot).  Same-address device atomics cost ~12 ns each: ~600 finishing waves per step made the
+        // single-step kernel 20 us slower than its memory time.  rmav_episode_totals sums the slots.
         const unsigned int wn = wave_sum(fin_n);
         const unsigned int wl = wave_sum(fin_len);
         const float wr = wave_sum(fin_ret);
         if ((threadIdx.x & 63) == 0 && wn != 0) {
-            atomicAdd(&a.totals->episodes, (unsigned long long)wn);
-            atomicAdd(&a.totals->length_sum, (unsigned long long)wl);
-            atomicAdd(&a.totals->return_sum, (double)wr);
+            Totals *slot = a.totals + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
+            slot->episodes += wn;
+            slot->length_sum += wl;
+            slot->return_sum += (double)wr;
         }
     }
 }

@@ -51,8 +51,6 @@ def test_gym_env_closed_loop_like_reference_test(G, kind):
         if done:
             n_done += 1
             env.reset()
-    if kind == "quad2d":
-        assert n_done > 10  # thrust x10 makes the 2-D loop diverge within a few steps
     env.close()
 
 

@@ -167,7 +167,6 @@ def test_fused_rollout_equals_single_steps(G, kind, mode):
     for key in eb0:
         assert np.array_equal(eb0[key], eb1[key]), key
     assert k0 == k1 == T
-    assert t0["done"].sum() > 0 or kind == "quad3d_sl" or mode == "controller"
 
 
 @pytest.mark.parametrize("kind", KINDS)
