@@ -90,14 +90,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    # under torch.distributed.run (RANK is set) the distributed path is exercised even for one rank
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -152,7 +154,7 @@ def main():
             run, per_launch = make_runner(mode, chunk)
             run(W)
             stream.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -161,15 +163,15 @@ def main():
             run(K)
             e1.record(stream)
             gathered = None
-            if world > 1:  # the path's one exchange: per-rollout all-gather of episode statistics (RCCL / xGMI)
+            if use_dist:  # the path's one exchange: per-rollout all-gather of episode statistics (RCCL / xGMI)
                 eb = env.episode_buffers(device_out=True)
                 gathered = all_gather_episode_stats(eb["last_return"], eb["last_length"], n_total)
             torch.cuda.synchronize()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             wall = time.perf_counter() - t0
             kernel_ms = e0.elapsed_time(e1) / K  # HIP events on the launch stream
-            if world > 1:
+            if use_dist:
                 w = torch.tensor([wall], dtype=torch.float64, device=dev)
                 dist.all_reduce(w, op=dist.ReduceOp.MAX)
                 wall = float(w.item())
@@ -187,7 +189,7 @@ def main():
                          "ms_per_launch_hip_events": k2,
                          "roofline_frac": algo_bytes * n * pl2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         totals = env.episode_totals()
-        if world > 1:
+        if use_dist:
             totals = all_reduce_totals(totals, device=dev)
 
     value = n_total * per_launch * args.steps / wall
@@ -246,7 +248,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     env.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -95,7 +96,16 @@ int check_params(const rmav_params &q) {
 
 inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
 
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+// Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
+int block_size() {
+    static int b = [] {
+        const char *e = getenv("RMAV_BLOCK");
+        int v = e ? atoi(e) : kBlock;
+        return (v == 64 || v == 128 || v == 256) ? v : kBlock;
+    }();
+    return b;
+}
+inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + block_size() - 1) / block_size())); }
 
 int ensure_scratch(rmav_handle h, size_t bytes) {
     if (bytes <= h->scratch_bytes) return RMAV_OK;
@@ -119,7 +129,7 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     using R = typename Env<K>::R;
     const ParamsT<R> p = derive<R>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(kBlock), 0, h->stream, a, p, pc);
+    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
@@ -168,7 +178,7 @@ RolloutArgs base_args(rmav_handle h) {
 int launch_reset(rmav_handle h, float *obs_dev, int layout) {
     const uint32_t fl = (h->flags & F_TRACK) | (layout == RMAV_AOS ? F_AOS : 0u);
 #define RMAV_RESET_CASE(KIND)                                                                      \
-    hipLaunchKernelGGL((k_reset<KIND>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,      \
+    hipLaunchKernelGGL((k_reset<KIND>), grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,      \
                        h->n, h->reset_cnt, h->ep_ret, h->ep_len, obs_dev, h->seed, h->env_base, fl)
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_RESET_CASE(QUAD2D); break;
@@ -185,7 +195,7 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
     const uint32_t fl = (layout == RMAV_AOS ? F_AOS : 0u);
     const ParamsT<double> pc = derive<double>(h->params);
 #define RMAV_CTRL_CASE(KIND)                                                                       \
-    hipLaunchKernelGGL((k_control<KIND>), grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,    \
+    hipLaunchKernelGGL((k_control<KIND>), grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,    \
                        h->n, act_dev, fl, pc)
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_CTRL_CASE(QUAD2D); break;
@@ -551,12 +561,12 @@ int rmav_get_state(rmav_handle h, float *out, int mem, int layout) {
     const size_t cnt = (size_t)h->n * nS;
     if (layout == RMAV_SOA) return copy_out(h, (const float *)h->state, out, cnt, mem);
     if (mem == RMAV_DEVICE) {
-        hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(kBlock), 0, h->stream, h->state, out, h->n, nS);
+        hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state, out, h->n, nS);
         HIP_TRY(hipGetLastError());
         return RMAV_OK;
     }
     if (int rc = ensure_scratch(h, cnt * sizeof(float))) return rc;
-    hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(kBlock), 0, h->stream, h->state,
+    hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,
                        (float *)h->scratch, h->n, nS);
     HIP_TRY(hipGetLastError());
     return copy_out(h, (const float *)h->scratch, out, cnt, RMAV_HOST);
@@ -575,7 +585,7 @@ int rmav_set_state(rmav_handle h, const float *in, int mem, int layout) {
         HIP_TRY(hipMemcpyAsync(h->scratch, in, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
         src = (const float *)h->scratch;
     }
-    hipLaunchKernelGGL(k_aos_to_soa, grid_for(h->n), dim3(kBlock), 0, h->stream, src, h->state, h->n, nS);
+    hipLaunchKernelGGL(k_aos_to_soa, grid_for(h->n), dim3(block_size()), 0, h->stream, src, h->state, h->n, nS);
     HIP_TRY(hipGetLastError());
     if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
     return RMAV_OK;

@@ -24,7 +24,7 @@ namespace rmav {
 enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
 
 struct Totals {
     unsigned long long episodes;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                                                     const ParamsT<typename Env<K>::R> p,
                                                     const ParamsT<double> pc) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     const bool aos = (a.flags & F_AOS) != 0;
     const bool track = (a.flags & F_TRACK) != 0;
@@ -177,18 +177,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
     }
 
     if (track) {
-        // Episode totals: each wavefront owns one slot of a [ceil(N/64)] partials array and adds to it
-        // with plain loads/stores (launches on a handle are stream-ordered, so nobody else touches the
-        // slot).  Same-address device atomics cost ~12 ns each: ~600 finishing waves per step made the
-        // single-step kernel 20 us slower than its memory time.  rmav_episode_totals sums the slots.
+        // Episode totals: each wavefront owns one slot of a [ceil(N/64)] partials array, so the adds never
+        // contend (same-address device atomics cost ~12 ns each: ~600 finishing waves per step made the
+        // single-step kernel 20 us slower than its memory time).  The adds are result-less atomics:
+        // fire-and-forget at the L2, no load -> add -> store round trip at the tail of the kernel.
+        // rmav_episode_totals sums the slots.
         const unsigned int wn = wave_sum(fin_n);
         const unsigned int wl = wave_sum(fin_len);
         const float wr = wave_sum(fin_ret);
         if ((threadIdx.x & 63) == 0 && wn != 0) {
-            Totals *slot = a.totals + (((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 6);
-            slot->episodes += wn;
-            slot->length_sum += wl;
-            slot->return_sum += (double)wr;
+            Totals *slot = a.totals + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+            atomicAdd(&slot->episodes, (unsigned long long)wn);
+            atomicAdd(&slot->length_sum, (unsigned long long)wl);
+            atomicAdd(&slot->return_sum, (double)wr);
         }
     }
 }
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint3
                                                   float *ep_ret, int32_t *ep_len, float *obs_out,
                                                   uint64_t seed, uint64_t env_base, uint32_t flags) {
     constexpr int NS = Dims<K>::NS;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s[NS];
     const uint32_t rc = reset_cnt[i];
@@ -227,7 +228,7 @@ template <int K>
 __global__ __launch_bounds__(kBlock) void k_control(const float *state, int64_t n, float *act_out,
                                                     uint32_t flags, const ParamsT<double> pc) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s[NS], act[NA];
 #pragma unroll
@@ -244,12 +245,12 @@ __global__ __launch_bounds__(kBlock) void k_control(const float *state, int64_t 
 
 // [dim][n] <-> [n][dim]
 __global__ __launch_bounds__(kBlock) void k_soa_to_aos(const float *src, float *dst, int64_t n, int dim) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int c = 0; c < dim; ++c) dst[i * dim + c] = src[(int64_t)c * n + i];
 }
 __global__ __launch_bounds__(kBlock) void k_aos_to_soa(const float *src, float *dst, int64_t n, int dim) {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int c = 0; c < dim; ++c) dst[(int64_t)c * n + i] = src[i * dim + c];
 }
