@@ -325,7 +325,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (kind < 0 || kind > 3) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
-    if (n_envs <= 0 || n_envs > ((int64_t)1 << 31) * kBlock)
+    if (n_envs <= 0 || n_envs > ((int64_t)1 << 25))  // 32-bit buffer offsets, see rmav_kernels.hpp
         return fail(RMAV_ERR_INVALID, "n_envs out of range: %lld", (long long)n_envs);
     if (flags & ~(RMAV_F_AUTO_RESET | RMAV_F_TRACK_EPISODES))
         return fail(RMAV_ERR_INVALID, "unknown flag bits 0x%x", flags);

@@ -61,13 +61,41 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
     return v;
 }
 
+// SoA accesses go through buffer instructions: a 128-bit resource descriptor (base address) and the
+// per-component offset c*N*4 live in scalar registers (SALU arithmetic, issued beside the VALU stream),
+// and the lane supplies only its 32-bit byte offset:   buffer_load_dword v, v_off, s[rsrc], s_coff offen.
+// With plain pointers hipcc rebuilt a 64-bit per-lane address with VALU ops for every one of the
+// 14 loads / 16-31 stores of a step (35 v_lshl_add_u64 per step, 88 -> 59 VGPRs for quad3d after the
+// change).  Limits: lane offset 4*N and column offset 4*nS*N must fit 32 bits, hence N <= 2^25 envs
+// per handle (rmav_create enforces it).
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
+    // raw buffer (stride 0), bounds check disabled (num_records = 2^32-1; lanes are predicated by
+    // li < N), word 3 = 0x00020000: the gfx9/CDNA raw-dword format
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ int32_t buf_ld_i32(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t soff, int32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, r, voff, soff, 0);
+}
+
 template <int K, int MODE>
 __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                                                     const ParamsT<typename Env<K>::R> p,
                                                     const ParamsT<double> pc) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;  // local env index
     const int64_t n = a.n;
+    const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
+    const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
     const bool track = (a.flags & F_TRACK) != 0;
     const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
@@ -75,53 +103,63 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
 
-    if (i < n) {
+    if (li < (uint64_t)n) {
+        const rsrc_t r_state = make_rsrc(a.state);
         float s[NS];
 #pragma unroll
-        for (int c = 0; c < NS; ++c) s[c] = a.state[(int64_t)c * n + i];
+        for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
         float er = 0.0f;
         int32_t el = 0;
         if (track) {
-            er = a.ep_ret[i];
-            el = a.ep_len[i];
+            er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+            el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
         }
         // steps_beyond_done and the reset counter ride in registers for the whole launch: loading them
         // on demand (only lanes that terminate need them) would put one or two dependent HBM round
         // trips into every step of every wavefront that has a finishing lane (~57 % of them at the
         // 1.3 %/step termination rate of random actions).
-        int32_t sb = a.sbd[i];
-        uint32_t rc = a.reset_cnt[i];
+        int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+        uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
         const int32_t sb0 = sb;
         const uint32_t rc0 = rc;
-        const uint64_t env_id = a.env_base + (uint64_t)i;
+        const uint64_t env_id = a.env_base + (uint64_t)li;
+
+        // uniform cursors into the time-major trajectory buffers, advanced once per step
+        const float *act_in = a.act_in;
+        float *act_out = (MODE != ACT_BUFFER) ? a.act_out : nullptr;
+        float *obs_out = a.obs_out;
+        float *rew_out = a.rew_out;
+        uint8_t *done_out = a.done_out;
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
             if constexpr (MODE == ACT_BUFFER) {
                 if (aos) {
-                    const float *src = a.act_in + ((int64_t)k * n + i) * NA;
+                    const float *src = act_in + (int64_t)li * NA;
 #pragma unroll
                     for (int c = 0; c < NA; ++c) act[c] = src[c];
                 } else {
-                    const float *src = a.act_in + (int64_t)k * NA * n + i;
+                    const rsrc_t r = make_rsrc(act_in);
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) act[c] = src[(int64_t)c * n];
+                    for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * col);
                 }
+                act_in += (int64_t)NA * n;
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else {
                 env_control<K>(s, pc, act);
             }
-            if (MODE != ACT_BUFFER && a.act_out) {
+            if (act_out) {
                 if (aos) {
-                    float *dst = a.act_out + ((int64_t)k * n + i) * NA;
+                    float *dst = act_out + (int64_t)li * NA;
 #pragma unroll
                     for (int c = 0; c < NA; ++c) dst[c] = act[c];
                 } else {
-                    float *dst = a.act_out + (int64_t)k * NA * n + i;
+                    const rsrc_t r = make_rsrc(act_out);
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) dst[(int64_t)c * n] = act[c];
+                    for (int c = 0; c < NA; ++c) buf_st(r, off, (uint32_t)c * col, act[c]);
                 }
+                act_out += (int64_t)NA * n;
             }
 
             float dist;
@@ -138,8 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                 er += r;
                 el += 1;
                 if (done) {
-                    a.last_ret[i] = er;
-                    a.last_len[i] = el;
+                    buf_st(make_rsrc(a.last_ret), off, 0, er);
+                    buf_st_i32(make_rsrc(a.last_len), off, 0, el);
                     fin_n += 1;
                     fin_len += (unsigned int)el;
                     fin_ret += er;
@@ -151,29 +189,36 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                 reset_state<K>(a.seed, env_id, rc, s);
                 rc += 1;
             }
-            if (a.obs_out) {
+            if (obs_out) {
                 if (aos) {
-                    float *dst = a.obs_out + ((int64_t)k * n + i) * NS;
+                    float *dst = obs_out + (int64_t)li * NS;
 #pragma unroll
                     for (int c = 0; c < NS; ++c) dst[c] = s[c];
                 } else {
-                    float *dst = a.obs_out + (int64_t)k * NS * n + i;
+                    const rsrc_t ro = make_rsrc(obs_out);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) dst[(int64_t)c * n] = s[c];
+                    for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
                 }
+                obs_out += (int64_t)NS * n;
             }
-            if (a.rew_out) a.rew_out[(int64_t)k * n + i] = r;
-            if (a.done_out) a.done_out[(int64_t)k * n + i] = done ? 1 : 0;
+            if (rew_out) {
+                buf_st(make_rsrc(rew_out), off, 0, r);
+                rew_out += n;
+            }
+            if (done_out) {
+                __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(done_out), li, 0, 0);
+                done_out += n;
+            }
         }
 
 #pragma unroll
-        for (int c = 0; c < NS; ++c) a.state[(int64_t)c * n + i] = s[c];
+        for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
         if (track) {
-            a.ep_ret[i] = er;
-            a.ep_len[i] = el;
+            buf_st(make_rsrc(a.ep_ret), off, 0, er);
+            buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
         }
-        if (sb != sb0) a.sbd[i] = sb;
-        if (rc != rc0) a.reset_cnt[i] = rc;
+        if (sb != sb0) buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
+        if (rc != rc0) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     }
 
     if (track) {
@@ -186,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
         const unsigned int wl = wave_sum(fin_len);
         const float wr = wave_sum(fin_ret);
         if ((threadIdx.x & 63) == 0 && wn != 0) {
-            Totals *slot = a.totals + (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+            Totals *slot = a.totals + (li >> 6);
             atomicAdd(&slot->episodes, (unsigned long long)wn);
             atomicAdd(&slot->length_sum, (unsigned long long)wl);
             atomicAdd(&slot->return_sum, (double)wr);
