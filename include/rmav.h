@@ -139,6 +139,11 @@ int rmav_destroy(rmav_handle h);
 int rmav_seed(rmav_handle h, uint64_t seed);
 int rmav_get_params(rmav_handle h, rmav_params *out);
 int rmav_set_params(rmav_handle h, const rmav_params *in);
+/* Rebind the handle to another HIP stream the caller owns (NULL: back to a stream owned by the
+ * handle).  Pending work on the old stream is waited for first.  Lets a caller capture rmav_step /
+ * rmav_rollout launches (mem = RMAV_DEVICE: no allocation, no synchronisation) into a hipGraph on its
+ * capture stream. */
+int rmav_set_stream(rmav_handle h, void *hip_stream);
 int64_t rmav_num_envs(rmav_handle h); /* < 0 on a bad handle */
 int rmav_sync(rmav_handle h);         /* waits for everything enqueued on the handle's stream */
 

@@ -437,6 +437,22 @@ int rmav_set_params(rmav_handle h, const rmav_params *in) {
     return RMAV_OK;
 }
 
+int rmav_set_stream(rmav_handle h, void *hip_stream) {
+    CHECK_HANDLE(h);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->own_stream) {
+        (void)hipStreamDestroy(h->stream);
+        h->own_stream = false;
+    }
+    if (hip_stream) {
+        h->stream = (hipStream_t)hip_stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+        h->own_stream = true;
+    }
+    return RMAV_OK;
+}
+
 int64_t rmav_num_envs(rmav_handle h) {
     if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
     return h->n;

@@ -124,6 +124,22 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
         const uint32_t rc0 = rc;
         const uint64_t env_id = a.env_base + (uint64_t)li;
 
+        // Spare reset state.  PMC counters (profiles/r01) show the fused kernel is instruction-issue bound
+        // at C2: one wavefront per SIMD, ~4 cycles per instruction, SQ_ACTIVE_INST_ANY = 75 % of
+        // SQ_WAVE_CYCLES.  Only ~1.3 % of the lanes terminate per step, but 57 % of the wavefronts
+        // contain one, and each of those then executes the three Philox calls of reset_state() for the
+        // whole wavefront: ~128 of the ~305 VALU instructions of an average step.  The state an env
+        // will be reset to depends only on (seed, env id, reset counter), so for multi-step launches it
+        // is drawn ONCE up front (all lanes busy, amortised over the launch) and the in-loop reset
+        // becomes a predicated register copy.  A second termination of the same env inside one launch
+        // falls back to drawing on demand.  Same counters, same bits either way.
+        float spare[NS];
+        bool have_spare = false;
+        if (auto_reset && a.n_steps >= 8) {
+            reset_state<K>(a.seed, env_id, rc, spare);
+            have_spare = true;
+        }
+
         // uniform cursors into the time-major trajectory buffers, advanced once per step
         const float *act_in = a.act_in;
         float *act_out = (MODE != ACT_BUFFER) ? a.act_out : nullptr;
@@ -186,7 +202,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                 }
             }
             if (done && auto_reset) {
-                reset_state<K>(a.seed, env_id, rc, s);
+                if (have_spare) {
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) s[c] = spare[c];
+                    have_spare = false;
+                } else {
+                    reset_state<K>(a.seed, env_id, rc, s);
+                }
                 rc += 1;
             }
             if (obs_out) {

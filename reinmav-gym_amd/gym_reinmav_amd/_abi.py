@@ -74,6 +74,7 @@ PROTOTYPES = {
     "rmav_seed": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rmav_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "rmav_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "rmav_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rmav_num_envs": (C.c_int64, [C.c_void_p]),
     "rmav_sync": (C.c_int, [C.c_void_p]),
     "rmav_reset": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),

@@ -78,6 +78,12 @@ class BatchedQuadrotor:
     def seed(self, seed: int):
         A.check(self._lib.rmav_seed(self._h, int(seed) & (2**64 - 1)))
 
+    def use_stream(self, torch_stream=None):
+        """Rebind to a torch stream (default: torch's current stream on this device)."""
+        st = torch_stream if torch_stream is not None else torch.cuda.current_stream(self.device)
+        self._tstream = st
+        A.check(self._lib.rmav_set_stream(self._h, C.c_void_p(st.cuda_stream or 1)))
+
     def sync(self):
         A.check(self._lib.rmav_sync(self._h))
 

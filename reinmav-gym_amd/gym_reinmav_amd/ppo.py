@@ -1,0 +1,216 @@
+"""PPO2-style rollout collection (and a minimal learner) on top of the batched HIP envs.
+
+This is the *caller* side of the hot path: what ``python -m gym_reinmav.run --alg=ppo2 --env=quadrotor3d-v0
+--network=mlp`` does through baselines (``gym_reinmav/run.py:63-68``: ``learn(env=...)`` whose ``Runner``
+alternates ``model.step(obs)`` and ``env.step(actions)``, then GAE(lambda) and clipped-surrogate
+minibatch epochs).  baselines / TensorFlow 1 are third party and absent; the hyper-parameters below are
+baselines' documented ppo2 defaults (nsteps 2048 for ONE env - here the batch is 10^4-10^6 envs, so a
+rollout is ``nsteps`` x N transitions with a small ``nsteps``).
+
+MI355X-first choices:
+* everything stays on the GPU: observations never leave HBM, ``env.step`` receives the action tensor's
+  device pointer and writes obs / reward / done straight into the rollout buffers (zero copies);
+* **feature-major layout end to end**: the env's native layout is SoA ``[dim, N]``; the policy computes
+  ``W @ X`` on ``X = obs[nS, N]`` and emits actions ``[nA, N]``, so neither side ever transposes and
+  every env access stays coalesced (no AoS emit needed);
+* the whole T-step rollout (policy + env launches) can be captured in ONE hipGraph
+  (``RolloutCollector(graph=True)``): ``rmav_step`` with device pointers allocates nothing and never
+  synchronises, so it is capturable; replay removes ~10 eager launches of host overhead per env-step;
+* data parallel over GPUs = env sharding; gradients are averaged with one flat all-reduce per minibatch
+  (~10 k parameters: latency-bound on xGMI, so a single bucket).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from .core import BatchedQuadrotor
+
+
+class MlpPolicy(torch.nn.Module):
+    """baselines ``mlp`` (2 x 64 tanh) Gaussian policy + separate value net, in feature-major form."""
+
+    def __init__(self, n_obs: int, n_act: int, hidden: int = 64, init_logstd: float = 0.0):
+        super().__init__()
+        mk = lambda i, o: torch.nn.Linear(i, o)  # noqa: E731
+        self.pi = torch.nn.ModuleList([mk(n_obs, hidden), mk(hidden, hidden), mk(hidden, n_act)])
+        self.vf = torch.nn.ModuleList([mk(n_obs, hidden), mk(hidden, hidden), mk(hidden, 1)])
+        self.logstd = torch.nn.Parameter(torch.full((n_act,), float(init_logstd)))
+        for net, last_gain in ((self.pi, 0.01), (self.vf, 1.0)):
+            for i, lin in enumerate(net):
+                torch.nn.init.orthogonal_(lin.weight, gain=last_gain if i == 2 else math.sqrt(2.0))
+                torch.nn.init.zeros_(lin.bias)
+
+    @staticmethod
+    def _mlp(net, x):  # x [in, N] -> [out, N]
+        for i, lin in enumerate(net):
+            x = torch.addmm(lin.bias[:, None], lin.weight, x)
+            if i < 2:
+                x = torch.tanh(x)
+        return x
+
+    def forward(self, obs_fm: torch.Tensor):
+        """obs_fm [nS, N] -> (mean [nA, N], value [N])."""
+        return self._mlp(self.pi, obs_fm), self._mlp(self.vf, obs_fm)[0]
+
+    def log_prob(self, mean, act):
+        z = (act - mean) * torch.exp(-self.logstd)[:, None]
+        return -0.5 * (z * z).sum(0) - self.logstd.sum() - 0.5 * mean.shape[0] * math.log(2 * math.pi)
+
+    def entropy(self):
+        return (self.logstd + 0.5 * math.log(2 * math.pi * math.e)).sum()
+
+
+class RolloutCollector:
+    """Collects ``nsteps`` transitions of every env into device-resident, time-major, feature-major buffers."""
+
+    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, graph: bool = False):
+        assert env.auto_reset, "rollouts need VecEnv semantics (auto-reset)"
+        self.env, self.policy, self.T = env, policy, int(nsteps)
+        dev = torch.device("cuda", env.device)
+        N, nS, nA, T = env.num_envs, env.nS, env.nA, self.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.obs = torch.empty((T + 1, nS, N), **f32)   # obs[t] is the observation action t was computed from
+        self.act = torch.empty((T, nA, N), **f32)
+        self.logp = torch.empty((T, N), **f32)
+        self.val = torch.empty((T + 1, N), **f32)
+        self.rew = torch.empty((T, N), **f32)
+        self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
+        self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
+        self._graph = None
+        if graph:
+            self._capture()
+
+    # one env-step of the loop baselines' Runner.run() executes (model.step -> env.step)
+    def _step(self, t: int):
+        mean, v = self.policy(self.obs[t])
+        noise = torch.randn_like(mean)
+        torch.addcmul(mean, noise, torch.exp(self.policy.logstd)[:, None], out=self.act[t])
+        self.logp[t] = -0.5 * (noise * noise).sum(0) - self.policy.logstd.sum() - 0.5 * mean.shape[0] * math.log(2 * math.pi)
+        self.val[t] = v
+        self.env.step(self.act[t], layout="soa", out=(self.obs[t + 1], self.rew[t], self.done[t]))
+
+    def _body(self):
+        with torch.no_grad():
+            for t in range(self.T):
+                self._step(t)
+            self.val[self.T] = self.policy(self.obs[self.T])[1]
+
+    def _capture(self):
+        env = self.env
+        side = torch.cuda.Stream(device=env.device)
+        side.wait_stream(torch.cuda.current_stream(env.device))
+        state = env.get_state(layout="soa", device_out=True)  # warm-up must not advance the envs for the caller
+        sbd, rc = env.get_sbd(), env.get_reset_counts()
+        with torch.cuda.stream(side):
+            env.use_stream(side)
+            self._body()                                        # warm-up (allocator, lazy inits)
+            side.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                self._body()
+        self._graph = g
+        cur = torch.cuda.current_stream(env.device)
+        cur.wait_stream(side)
+        env.use_stream(cur)                                     # replays run on the caller's current stream
+        env.set_state(state, layout="soa")                      # restore: capture itself does not execute,
+        env.set_sbd(sbd)                                        # but the warm-up did
+        env.set_reset_counts(rc)
+        self.obs[0].copy_(state)
+
+    def collect(self):
+        """Run one rollout; buffers are valid after the current stream's work completes."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body()
+        return self
+
+    def roll_over(self):
+        """Make the last observation the first one of the next rollout."""
+        self.obs[0].copy_(self.obs[self.T])
+
+
+def gae(rew, val, done, gamma: float = 0.99, lam: float = 0.95):
+    """Generalised advantage estimation on time-major device tensors.
+
+    rew [T,N], val [T+1,N] (val[T] = bootstrap value), done [T,N] (1 = the episode ended with step t; the
+    next obs is a fresh reset and must not be bootstrapped from).  Returns (adv [T,N], returns [T,N])."""
+    T = rew.shape[0]
+    adv = torch.empty_like(rew)
+    last = torch.zeros_like(rew[0])
+    nonterm = 1.0 - done.to(rew.dtype)
+    for t in range(T - 1, -1, -1):
+        delta = rew[t] + gamma * val[t + 1] * nonterm[t] - val[t]
+        last = delta + gamma * lam * nonterm[t] * last
+        adv[t] = last
+    return adv, adv + val[:T]
+
+
+class PPO:
+    """Clipped-surrogate PPO (baselines ppo2 defaults: lr 3e-4, clip 0.2, 4 epochs x 4 minibatches,
+    vf_coef 0.5, ent_coef 0, max_grad_norm 0.5, gamma 0.99, lambda 0.95)."""
+
+    def __init__(self, policy: MlpPolicy, lr: float = 3e-4, clip: float = 0.2, epochs: int = 4, minibatches: int = 4,
+                 vf_coef: float = 0.5, ent_coef: float = 0.0, max_grad_norm: float = 0.5, gamma: float = 0.99,
+                 lam: float = 0.95):
+        self.policy = policy
+        self.opt = torch.optim.Adam(policy.parameters(), lr=lr, eps=1e-5)
+        self.clip, self.epochs, self.minibatches = clip, epochs, minibatches
+        self.vf_coef, self.ent_coef, self.max_grad_norm, self.gamma, self.lam = vf_coef, ent_coef, max_grad_norm, gamma, lam
+
+    def _allreduce_grads(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        params = [p for p in self.policy.parameters() if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in params])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= dist.get_world_size()
+        o = 0
+        for p in params:
+            n = p.grad.numel()
+            p.grad.copy_(flat[o:o + n].view_as(p.grad))
+            o += n
+
+    def update(self, ro: RolloutCollector) -> dict:
+        T, N = ro.rew.shape
+        adv, ret = gae(ro.rew, ro.val, ro.done, self.gamma, self.lam)
+        obs = ro.obs[:T].permute(1, 0, 2).reshape(ro.obs.shape[1], T * N)   # [nS, T*N] feature-major
+        act = ro.act.permute(1, 0, 2).reshape(ro.act.shape[1], T * N)
+        logp_old, val_old = ro.logp.reshape(-1), ro.val[:T].reshape(-1)
+        adv, ret = adv.reshape(-1), ret.reshape(-1)
+        stats = {}
+        B = T * N
+        mb = B // self.minibatches
+        for _ in range(self.epochs):
+            perm = torch.randperm(B, device=obs.device)
+            for i in range(self.minibatches):
+                idx = perm[i * mb:(i + 1) * mb]
+                a = adv[idx]
+                a = (a - a.mean()) / (a.std() + 1e-8)
+                mean, v = self.policy(obs[:, idx])
+                logp = self.policy.log_prob(mean, act[:, idx])
+                ratio = torch.exp(logp - logp_old[idx])
+                pg = torch.max(-a * ratio, -a * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)).mean()
+                v_clip = val_old[idx] + torch.clamp(v - val_old[idx], -self.clip, self.clip)
+                vf = 0.5 * torch.max((v - ret[idx]) ** 2, (v_clip - ret[idx]) ** 2).mean()
+                loss = pg + self.vf_coef * vf - self.ent_coef * self.policy.entropy()
+                self.opt.zero_grad(set_to_none=True)
+                loss.backward()
+                self._allreduce_grads()
+                torch.nn.utils.clip_grad_norm_(self.policy.parameters(), self.max_grad_norm)
+                self.opt.step()
+                stats = {"pg_loss": pg.detach(), "vf_loss": vf.detach(), "ratio_max": ratio.detach().max()}
+        var_y = ret.var()
+        stats["explained_variance"] = 1.0 - (ret - val_old).var() / (var_y + 1e-8)
+        return {k: float(v) for k, v in stats.items()}
+
+
+def sync_parameters(policy: MlpPolicy, src: int = 0):
+    """Broadcast rank ``src``'s parameters (data-parallel start)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for p in policy.parameters():
+            dist.broadcast(p.data, src)
