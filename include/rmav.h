@@ -82,7 +82,8 @@ enum rmav_layout { RMAV_SOA = 0, RMAV_AOS = 1 };
 enum rmav_action_mode {
     RMAV_ACT_BUFFER = 0,    /* actions read from a caller buffer */
     RMAV_ACT_RANDOM = 1,    /* uniform in [act_lo, act_hi) from the counter RNG, generated in-kernel */
-    RMAV_ACT_CONTROLLER = 2 /* the reference's geometric controller, evaluated in-kernel */
+    RMAV_ACT_CONTROLLER = 2, /* the reference's geometric controller, evaluated in-kernel */
+    RMAV_ACT_POLICY = 3      /* Gaussian MLP policy evaluated in-kernel (rmav_rollout_policy only) */
 };
 
 /* rmav_create flags */
@@ -168,6 +169,24 @@ int rmav_control(rmav_handle h, float *actions_out, int mem, int layout);
 int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in,
                  float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
                  int layout, int fused);
+
+/* PPO2-style rollout with the policy inside the kernel (the caller loop of gym_reinmav/run.py:63-68:
+ * baselines ppo2 Runner = model.step(obs) -> env.step(actions), network='mlp').  Policy: two 64-unit tanh
+ * layers -> Gaussian mean (state-independent log-std), plus a value net of the same shape.  All pointers
+ * are DEVICE pointers, layout is SoA, nothing synchronises (capturable in a hipGraph).
+ * weights: rmav_policy_weight_count(kind) floats, 16-byte aligned, layout (H = 64, NSP = nS rounded up
+ *   to a multiple of 4), policy net then value net, each:
+ *     W1 [H][NSP] (row = hidden unit, zero padded) | b1 [H] | W2T [H][H] (W2T[i][j] = W2[j][i]) | b2 [H] |
+ *     W3T [H][4] (W3T[j][k] = W3[k][j], zero padded to 4 outputs) | b3 [4]
+ *   then logstd [4] (zero padded).
+ * Per step t: a = mean(obs_t) + exp(logstd) * z_t with z_t standard normal from the counter RNG
+ * (stream tag 3, Box-Muller; see csrc/rmav_policy.hpp), logp_out[t] = log N(a; mean, std),
+ * value_out[t] = V(obs_t); value_out[n_steps] = V(obs after the last step) for bootstrapping.
+ * actions_out [n_steps][nA][N], obs_out [n_steps][nS][N], rew_out / done_out [n_steps][N] may be NULL. */
+int64_t rmav_policy_weight_count(int kind);
+int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
+                        float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
+                        float *value_out);
 
 /* ---- state access (also the env checkpoint) ------------------------------------------------ */
 int rmav_get_state(rmav_handle h, float *out, int mem, int layout);      /* nS*N floats */

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -129,7 +130,8 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     using R = typename Env<K>::R;
     const ParamsT<R> p = derive<R>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
+    const size_t lds = (MODE == ACT_POLICY) ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL : 0;
+    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
@@ -139,6 +141,7 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     case RMAV_ACT_BUFFER: return launch_rollout_km<K, ACT_BUFFER>(h, a);
     case RMAV_ACT_RANDOM: return launch_rollout_km<K, ACT_RANDOM>(h, a);
     case RMAV_ACT_CONTROLLER: return launch_rollout_km<K, ACT_CONTROLLER>(h, a);
+    case RMAV_ACT_POLICY: return launch_rollout_km<K, ACT_POLICY>(h, a);
     }
     return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
@@ -548,6 +551,39 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
     } else if (actions_out && action_mode == RMAV_ACT_BUFFER && actions_out != actions_in) {
         HIP_TRY(hipMemcpyAsync(actions_out, actions_in, b_act, hipMemcpyDeviceToDevice, h->stream));
     }
+    return RMAV_OK;
+}
+
+int64_t rmav_policy_weight_count(int kind) {
+    switch (kind) {
+    case RMAV_QUAD2D: return PolicyLayout<5>::TOTAL;
+    case RMAV_QUAD2D_SL: return PolicyLayout<9>::TOTAL;
+    case RMAV_QUAD3D: return PolicyLayout<10>::TOTAL;
+    case RMAV_QUAD3D_SL: return PolicyLayout<16>::TOTAL;
+    }
+    return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+}
+
+int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
+                        float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
+                        float *value_out) {
+    CHECK_HANDLE(h);
+    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (!weights || !logp_out || !value_out)
+        return fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
+    if ((reinterpret_cast<uintptr_t>(weights) & 15u) != 0)
+        return fail(RMAV_ERR_INVALID, "weights must be 16-byte aligned");
+    RolloutArgs a = base_args(h);
+    a.n_steps = n_steps;
+    a.act_out = actions_out;
+    a.obs_out = obs_out;
+    a.rew_out = rew_out;
+    a.done_out = done_out;
+    a.policy_w = weights;
+    a.logp_out = logp_out;
+    a.val_out = value_out;
+    if (int rc = launch_rollout(h, RMAV_ACT_POLICY, a)) return rc;
+    h->t += (uint64_t)n_steps;
     return RMAV_OK;
 }
 

@@ -18,10 +18,11 @@
 #pragma once
 
 #include "rmav_math.hpp"
+#include "rmav_policy.hpp"
 
 namespace rmav {
 
-enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2 };
+enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
 constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
@@ -53,6 +54,10 @@ struct RolloutArgs {
     int32_t n_steps;
     uint32_t flags;
     float act_lo, act_hi;
+    // ACT_POLICY only
+    const float *policy_w;  // packed weights (rmav_policy.hpp layout), device memory
+    float *logp_out;        // [n_steps][N]
+    float *val_out;         // [n_steps + 1][N]
 };
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
@@ -103,6 +108,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
 
+    // ACT_POLICY: stage the policy weights into LDS once per launch (every thread of the block helps)
+    if constexpr (MODE == ACT_POLICY) {
+        constexpr int NW4 = PolicyLayout<NS>::TOTAL / 4;
+        const float4 *src = reinterpret_cast<const float4 *>(a.policy_w);
+        float4 *dst = reinterpret_cast<float4 *>(lds_w);
+        for (int q = threadIdx.x; q < NW4; q += blockDim.x) dst[q] = src[q];
+        __syncthreads();
+    }
+
     if (li < (uint64_t)n) {
         const rsrc_t r_state = make_rsrc(a.state);
         float s[NS];
@@ -147,9 +161,45 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
         float *rew_out = a.rew_out;
         uint8_t *done_out = a.done_out;
 
+        float *logp_out = a.logp_out;
+        float *val_out = a.val_out;
+        float pol_std[4] = {0.f, 0.f, 0.f, 0.f};
+        float pol_logp0 = 0.0f;   // - sum(logstd) - NA/2 * ln(2 pi)
+        if constexpr (MODE == ACT_POLICY) {
+            float sl = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const float ls = lds_w[PolicyLayout<NS>::LOGSTD + c];
+                pol_std[c] = expf(ls);
+                sl += ls;
+            }
+            pol_logp0 = -sl - 0.5f * (float)NA * 1.8378770664093453f;
+        }
+
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
-            if constexpr (MODE == ACT_BUFFER) {
+            if constexpr (MODE == ACT_POLICY) {
+                using PL = PolicyLayout<NS>;
+                XVec<PL::NSP> x;
+#pragma unroll
+                for (int c = 0; c < PL::NSP; ++c) x.v[c] = (c < NS) ? s[c] : 0.0f;
+                const float4 m4 = mlp_forward<NS>(x, 0u);
+                const float4 v4 = mlp_forward<NS>(x, (uint32_t)PL::NET);
+                const float mean[4] = {m4.x, m4.y, m4.z, m4.w};
+                const float val[1] = {v4.x};
+                float z[4];
+                gaussian4(a.seed, env_id, a.t0 + (uint64_t)k, z);
+                float q = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) {
+                    act[c] = rfma(pol_std[c], z[c], mean[c]);
+                    q = rfma(z[c], z[c], q);
+                }
+                buf_st(make_rsrc(logp_out), off, 0, rfma(-0.5f, q, pol_logp0));
+                buf_st(make_rsrc(val_out), off, 0, val[0]);
+                logp_out += n;
+                val_out += n;
+            } else if constexpr (MODE == ACT_BUFFER) {
                 if (aos) {
                     const float *src = act_in + (int64_t)li * NA;
 #pragma unroll
@@ -233,6 +283,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
             }
         }
 
+        if constexpr (MODE == ACT_POLICY) {   // bootstrap value of the state the rollout ends in
+            using PL = PolicyLayout<NS>;
+            XVec<PL::NSP> x;
+#pragma unroll
+            for (int c = 0; c < PL::NSP; ++c) x.v[c] = (c < NS) ? s[c] : 0.0f;
+            const float4 v4 = mlp_forward<NS>(x, (uint32_t)PL::NET);
+            buf_st(make_rsrc(val_out), off, 0, v4.x);
+        }
 #pragma unroll
         for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
         if (track) {

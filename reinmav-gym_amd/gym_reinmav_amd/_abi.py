@@ -19,7 +19,7 @@ STATE_DIM = {QUAD2D: 5, QUAD2D_SL: 9, QUAD3D: 10, QUAD3D_SL: 16}
 ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4}
 HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
-ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER = 0, 1, 2
+ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY = 0, 1, 2, 3
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
 
@@ -82,6 +82,8 @@ PROTOTYPES = {
     "rmav_control": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_rollout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int, C.c_int,
                                C.c_int]),
+    "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
+    "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp]),
     "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_set_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_get_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),

@@ -134,6 +134,73 @@ class RolloutCollector:
         self.obs[0].copy_(self.obs[self.T])
 
 
+def pack_policy_weights(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Flatten an ``MlpPolicy`` into the buffer layout ``rmav_rollout_policy`` reads (include/rmav.h):
+    per net  W1 [64][NSP] | b1 | W2^T [64][64] | b2 | W3^T [64][4] | b3 [4],  then logstd [4]."""
+    H = policy.pi[0].out_features
+    assert H == 64 and policy.pi[1].in_features == 64, "the in-kernel policy is the 2 x 64 baselines mlp"
+    nsp = (n_obs + 3) // 4 * 4
+    dev = policy.logstd.device
+    parts = []
+    for net in (policy.pi, policy.vf):
+        w1 = torch.zeros((H, nsp), device=dev)
+        w1[:, :n_obs] = net[0].weight.detach()
+        w3t = torch.zeros((H, 4), device=dev)
+        w3t[:, :net[2].out_features] = net[2].weight.detach().t()
+        b3 = torch.zeros(4, device=dev)
+        b3[:net[2].out_features] = net[2].bias.detach()
+        parts += [w1.reshape(-1), net[0].bias.detach(), net[1].weight.detach().t().contiguous().reshape(-1),
+                  net[1].bias.detach(), w3t.reshape(-1), b3]
+    ls = torch.zeros(4, device=dev)
+    ls[:policy.logstd.numel()] = policy.logstd.detach()
+    parts.append(ls)
+    flat = torch.cat([p.float() for p in parts])
+    if out is not None:
+        out.copy_(flat)
+        return out
+    return flat.contiguous()
+
+
+class FusedPolicyCollector:
+    """Same buffers and semantics as :class:`RolloutCollector`, but ONE kernel launch per rollout: the policy
+    (2 x 64 tanh MLP + value net, weights staged in LDS) is evaluated inside the rollout kernel by the lane
+    that owns the env (``rmav_rollout_policy``), so nothing but the trajectory touches HBM."""
+
+    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int):
+        import ctypes as C
+
+        from . import _abi as A
+
+        assert env.auto_reset, "rollouts need VecEnv semantics (auto-reset)"
+        self.env, self.policy, self.T = env, policy, int(nsteps)
+        self._C, self._A = C, A
+        dev = torch.device("cuda", env.device)
+        N, nS, nA, T = env.num_envs, env.nS, env.nA, self.T
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.obs = torch.empty((T + 1, nS, N), **f32)
+        self.act = torch.empty((T, nA, N), **f32)
+        self.logp = torch.empty((T, N), **f32)
+        self.val = torch.empty((T + 1, N), **f32)
+        self.rew = torch.empty((T, N), **f32)
+        self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
+        n_w = A.lib().rmav_policy_weight_count(env.kind)
+        self.weights = torch.empty(n_w, **f32)
+        assert self.weights.data_ptr() % 16 == 0
+        self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
+
+    def collect(self):
+        C, A = self._C, self._A
+        w = pack_policy_weights(self.policy, self.env.nS, out=self.weights)
+        assert w.numel() == self.weights.numel()
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        A.check(A.lib().rmav_rollout_policy(self.env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]),
+                                            p(self.rew), p(self.done), p(self.logp), p(self.val)))
+        return self
+
+    def roll_over(self):
+        self.obs[0].copy_(self.obs[self.T])
+
+
 def gae(rew, val, done, gamma: float = 0.99, lam: float = 0.95):
     """Generalised advantage estimation on time-major device tensors.
 

@@ -19,7 +19,7 @@ def G(built):
     return g
 
 
-def _check_rollout(kind, seed, ro, rc0):
+def _check_rollout(kind, seed, ro, rc0, base=0):
     import torch
 
     torch.cuda.synchronize()
@@ -35,7 +35,7 @@ def _check_rollout(kind, seed, ro, rc0):
         assert scaled_err(obs[t + 1].T[alive], o2[alive]).max() <= TOL
         assert scaled_err(rew[t][alive], r[alive]).max() <= TOL
         if done[t].any():  # auto-reset: next obs is the env's next reset state
-            assert np.array_equal(obs[t + 1].T[done[t]], O.reset_states(kind, seed, np.nonzero(done[t])[0], rc[done[t]]))
+            assert np.array_equal(obs[t + 1].T[done[t]], O.reset_states(kind, seed, base + np.nonzero(done[t])[0], rc[done[t]]))
         rc += done[t].astype(np.uint32)
     return rc
 
@@ -81,4 +81,84 @@ def test_ppo_learner_runs_and_fits_values(G):
     # the value net starts uncorrelated with the returns and must pick them up
     assert hist[-1]["explained_variance"] > max(0.02, hist[0]["explained_variance"])
     assert all(h["ratio_max"] < 5.0 for h in hist)
+    env.close()
+
+
+def _predicted_noise(seed, env_ids, t):
+    """Box-Muller over the Philox stream tag 3 (csrc/rmav_policy.hpp), in float32 like the kernel."""
+    z = np.zeros((len(env_ids), 4), np.float32)
+    for i, e in enumerate(env_ids):
+        r = O.philox([e & 0xFFFFFFFF, e >> 32, t & 0xFFFFFFFF, (3 << 24) | (((t >> 32) & 0xFFFF) << 8)],
+                     [seed & 0xFFFFFFFF, seed >> 32])
+        for p in range(2):
+            u1 = np.float32((int(r[2 * p]) >> 8) + 1) * np.float32(1.0 / 16777216.0)
+            u2 = np.float32(int(r[2 * p + 1]) >> 8) * np.float32(1.0 / 16777216.0)
+            rad = np.sqrt(np.float32(-2.0) * np.log(u1, dtype=np.float32), dtype=np.float32)
+            z[i, 2 * p] = rad * np.cos(2 * np.pi * float(u2))
+            z[i, 2 * p + 1] = rad * np.sin(2 * np.pi * float(u2))
+    return z
+
+
+@pytest.mark.parametrize("kind", ["quad3d", "quad3d_sl", "quad2d", "quad2d_sl"])
+def test_fused_policy_rollout_matches_torch_policy_and_oracle(G, kind):
+    """rmav_rollout_policy: in-kernel MLP == torch MlpPolicy (fp32, tol 2e-5 on means / values), the sampled
+    action is mean + std * (spec'd Philox/Box-Muller normal), logp is consistent, and every env step agrees
+    with the oracle."""
+    import torch
+    from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
+
+    torch.manual_seed(2)
+    N, T, seed, base = 512, 12, 21, 1000
+    env = G.BatchedQuadrotor(kind, N, seed=seed, env_id_base=base)
+    pol = MlpPolicy(env.nS, env.nA, init_logstd=0.7).cuda()
+    with torch.no_grad():  # make the heads non-trivial (default init has gain 0.01 on the action head)
+        for net in (pol.pi, pol.vf):
+            net[2].weight.mul_(30.0 if net is pol.pi else 1.0)
+            net[2].bias.uniform_(-0.5, 0.5)
+        pol.logstd.copy_(torch.linspace(-0.5, 0.7, env.nA))
+    ro = FusedPolicyCollector(env, pol, T)
+    rc = env.get_reset_counts()
+    t0 = env.step_count
+    for it in range(3):
+        ro.collect()
+        rc = _check_rollout(kind, seed, ro, rc, base)   # env side vs oracle, incl. auto-reset states
+        with torch.no_grad():
+            obs = ro.obs[:T].permute(1, 0, 2).reshape(env.nS, -1)
+            mean, val = pol(obs)
+            mean, val = mean.reshape(env.nA, T, N), val.reshape(T, N)
+            v_last = pol(ro.obs[T])[1]
+        assert (ro.val[:T] - val).abs().max() < 2e-5 * max(1.0, float(val.abs().max()))
+        assert (ro.val[T] - v_last).abs().max() < 2e-5 * max(1.0, float(v_last.abs().max()))
+        std = torch.exp(pol.logstd)[:, None, None]
+        z = ((ro.act.permute(1, 0, 2) - mean) / std)            # implied noise [nA, T, N]
+        logp_ref = -0.5 * (z * z).sum(0) - pol.logstd.sum() - 0.5 * env.nA * np.log(2 * np.pi)
+        assert (ro.logp - logp_ref).abs().max() < 2e-3
+        zc = z.detach().cpu().numpy()
+        assert abs(zc.mean()) < 0.08 and abs(zc.var() - 1.0) < 0.12 and np.abs(zc).max() < 6.5
+        for t in (0, T - 1):                                    # exact noise spec on a subset of envs
+            ids = np.arange(0, N, 37)
+            zp = _predicted_noise(seed, base + ids, t0 + it * T + t)[:, :env.nA]
+            assert np.abs(zc[:, t, ids].T - zp).max() < 2e-4 * 30
+        ro.roll_over()
+    assert env.step_count == t0 + 3 * T
+    env.close()
+
+
+def test_fused_policy_learner_loop(G):
+    import torch
+    from gym_reinmav_amd.ppo import PPO, FusedPolicyCollector, MlpPolicy
+
+    torch.manual_seed(0)
+    env = G.BatchedQuadrotor("quad3d", 8192, seed=0)
+    pol = MlpPolicy(env.nS, env.nA).cuda()
+    ro = FusedPolicyCollector(env, pol, 32)
+    ppo = PPO(pol)
+    hist = []
+    for it in range(10):
+        ro.collect()
+        hist.append(ppo.update(ro))
+        ro.roll_over()
+    assert all(np.isfinite(list(h.values())).all() for h in hist)
+    assert hist[-1]["explained_variance"] > max(0.02, hist[0]["explained_variance"])
+    assert all(h["ratio_max"] < 5.0 for h in hist)   # rollout logp (kernel) and learner logp (torch) agree
     env.close()

@@ -34,3 +34,24 @@ def test_box_space():
 
     b = Box(low=0.0, high=10.0, shape=(4,), dtype=np.float32)
     assert b.shape == (4,) and b.contains(b.sample()) and not b.contains(np.full(4, 11.0, np.float32))
+
+
+def test_trajectory_schema_roundtrip(tmp_path, golden):
+    """The .npz trajectory schema: write a (synthetic) SoA rollout, read it back in the shared [T, N, dim] form;
+    the golden closed-loop fixtures map onto the same schema."""
+    from gym_reinmav_amd.trajectory import from_golden, load_rollout, save_rollout
+
+    rng = np.random.RandomState(0)
+    T, N = 7, 5
+    ro = {"actions": rng.normal(size=(T, 4, N)).astype(np.float32), "obs": rng.normal(size=(T, 10, N)).astype(np.float32),
+          "rew": rng.normal(size=(T, N)).astype(np.float32), "done": (rng.uniform(size=(T, N)) < 0.2).astype(np.uint8)}
+    s0 = rng.normal(size=(10, N)).astype(np.float32)
+    p = tmp_path / "ro.npz"
+    save_rollout(p, "quad3d", s0, ro, layout="soa", meta={"seed": 3})
+    z = load_rollout(p)
+    assert z["kind"] == "quad3d" and z["meta"]["seed"] == 3 and z["meta"]["schema"] == 1
+    assert z["state"].shape == (T, N, 10) and z["action"].shape == (T, N, 4) and z["done"].dtype == bool
+    assert np.array_equal(z["state"][0], s0.T) and np.array_equal(z["state"][1:], z["next_obs"][:-1])
+    assert np.array_equal(z["next_obs"][2], ro["obs"][2].T)
+    g = from_golden(golden["quad3d"])
+    assert g["state"].shape == (400, 4, 10) and g["done"].shape == (400, 4)
