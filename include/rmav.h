@@ -67,7 +67,19 @@ extern "C" {
 
 typedef struct rmav_env_s *rmav_handle;
 
-enum rmav_kind { RMAV_QUAD2D = 0, RMAV_QUAD2D_SL = 1, RMAV_QUAD3D = 2, RMAV_QUAD3D_SL = 3 };
+enum rmav_kind {
+    RMAV_QUAD2D = 0,
+    RMAV_QUAD2D_SL = 1,
+    RMAV_QUAD3D = 2,
+    RMAV_QUAD3D_SL = 3,
+    /* ReinmavEnv (reinmav_env.py:51-352, id 'reinmav-v0'): 13-state rigid body [x y z dx dy dz qw qx qy qz p q r]
+     * with thrust + body torques -> motor mixing/clamp -> linear and angular acceleration, 50-or-51 Euler
+     * sub-steps of 1/5000 s per step, reward 90 and done = 1 on every step, reset() a no-op.  The reference's
+     * step() takes no action: that behaviour is RMAV_ACT_CONTROLLER (built-in PD controller on a min-jerk
+     * trajectory, evaluated every sub-step).  With RMAV_ACT_BUFFER / RANDOM / POLICY the 4 action components
+     * are (F, Mx, My, Mz) held over the step (an extension).  Each env carries its own clock (rmav_get_time). */
+    RMAV_REINMAV = 4
+};
 
 enum rmav_status {
     RMAV_OK = 0,
@@ -120,9 +132,9 @@ typedef struct rmav_ep_totals {
 int rmav_version(void);              /* returns RMAV_VERSION */
 const char *rmav_last_error(void);   /* thread-local, never NULL */
 int rmav_device_count(void);         /* number of visible GPUs, 0 if none (never negative) */
-int rmav_state_dim(int kind);        /* 5, 9, 10, 16; -1 for a bad kind */
-int rmav_action_dim(int kind);       /* 2, 2, 4, 4 */
-int rmav_algorithmic_bytes(int kind); /* bytes per env-step of SURVEY.md 8(d): 53, 85, 101, 149 */
+int rmav_state_dim(int kind);        /* 5, 9, 10, 16, 13; -1 for a bad kind */
+int rmav_action_dim(int kind);       /* 2, 2, 4, 4, 4 */
+int rmav_algorithmic_bytes(int kind); /* bytes per env-step of SURVEY.md 8(d): 53, 85, 101, 149, 125 */
 /* reading_2d selects how the unparsable quadrotor2d.py:95-98 is read: 'B' -> |p|>3 or |v|>2
  * (default when 0 is passed), 'A' -> |p|>3 or |v|>10.  Ignored for other kinds. */
 int rmav_default_params(int kind, int reading_2d, rmav_params *out);
@@ -195,6 +207,8 @@ int rmav_get_sbd(rmav_handle h, int32_t *out, int mem); /* steps_beyond_done per
 int rmav_set_sbd(rmav_handle h, const int32_t *in, int mem);
 int rmav_get_reset_counts(rmav_handle h, uint32_t *out, int mem); /* resets drawn so far per env */
 int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem);
+int rmav_get_time(rmav_handle h, double *out, int mem);  /* RMAV_REINMAV: per-env clock t (reinmav_env.py:72) */
+int rmav_set_time(rmav_handle h, const double *in, int mem);
 int rmav_get_step_count(rmav_handle h, uint64_t *out); /* global step counter t */
 int rmav_set_step_count(rmav_handle h, uint64_t t);
 

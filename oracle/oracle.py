@@ -201,3 +201,51 @@ def rollout_random(kind: str, state: np.ndarray, sbd: np.ndarray, episode: np.nd
                                     sbd.ctypes.data_as(C.POINTER(C.c_int32)),
                                     episode.ctypes.data_as(C.POINTER(C.c_uint32)), t0, C.byref(ret), C.byref(nd))
     return int(k), ret.value, int(nd.value)
+
+
+# ---- ReinmavEnv (reinmav_env.py) ----------------------------------------------------------------------
+class ReinmavParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("arm_length", "mass", "gravity", "min_force", "max_force")] + [
+        ("inertia", C.c_double * 9), ("inv_inertia", C.c_double * 9)] + [
+        (n, C.c_double) for n in ("dt", "ds", "t_max")] + [(n, C.c_double * 3) for n in ("kp", "kd", "kp_rot", "kd_rot")]
+
+
+REINMAV_INIT_STATE = np.array([0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], dtype=np.float64)  # reinmav_env.py:79
+
+
+def reinmav_params() -> ReinmavParams:
+    p = ReinmavParams()
+    lib().oracle_reinmav_default_params(C.byref(p))
+    return p
+
+
+def reinmav_step(s, t: float, action=None, params: ReinmavParams | None = None):
+    """One env, one step (50/51 Euler sub-steps).  Returns (s_next f64[13], t_next, reward, done, n_substeps)."""
+    L = lib()
+    L.oracle_reinmav_step.restype = C.c_int
+    p = params or reinmav_params()
+    s = np.array(s, dtype=np.float64, copy=True)
+    tt = C.c_double(float(t))
+    r, d = C.c_double(), C.c_int()
+    a = None if action is None else np.ascontiguousarray(action, dtype=np.float64)
+    n = L.oracle_reinmav_step(C.byref(p), _dptr(s), C.byref(tt), None if a is None else _dptr(a), C.byref(r), C.byref(d))
+    return s, tt.value, r.value, bool(d.value), n
+
+
+def reinmav_batch_step(S, T, actions=None, params: ReinmavParams | None = None):
+    """S [n,13], T [n] -> (S_next [n,13], T_next [n], n_substeps [n])."""
+    p = params or reinmav_params()
+    S = np.array(S, dtype=np.float64, copy=True)
+    T = np.array(T, dtype=np.float64, copy=True)
+    ns = np.zeros(len(S), np.int32)
+    for i in range(len(S)):
+        S[i], T[i], _, _, ns[i] = reinmav_step(S[i], T[i], None if actions is None else actions[i], p)
+    return S, T, ns
+
+
+def reinmav_controller(s, t: float, params: ReinmavParams | None = None) -> np.ndarray:
+    p = params or reinmav_params()
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    fm = np.zeros(4)
+    lib().oracle_reinmav_controller(C.byref(p), _dptr(s), C.c_double(float(t)), _dptr(fm))
+    return fm

@@ -311,6 +311,61 @@ def load_class(kind: str, reading_2d: str = "B"):
     return cls
 
 
+def load_reinmav_class():
+    """The reference's fifth native env (reinmav_env.py): 13-state rigid body with a built-in PD controller
+    and min-jerk trajectory; step() takes no action.  Needs a matplotlib stand-in (the file selects the
+    TkAgg backend at import, reinmav_env.py:43-45)."""
+    if not available():
+        raise RuntimeError("reference tree not present (expected on the GPU box)")
+    if "reinmav" in _CACHE:
+        return _CACHE["reinmav"]
+    _install_stubs()
+    if "matplotlib" not in sys.modules or not getattr(sys.modules["matplotlib"], "_rmav_stub", False):
+        mpl = types.ModuleType("matplotlib")
+        mpl._rmav_stub = True
+        mpl.use = lambda *a, **k: None
+        plt = types.ModuleType("matplotlib.pyplot")
+        mpl.pyplot = plt
+        sys.modules["matplotlib"], sys.modules["matplotlib.pyplot"] = mpl, plt
+    path = os.path.join(NATIVE_DIR, "reinmav_env.py")
+    with open(path, "r") as f:
+        src = f.read()
+    mod = types.ModuleType("rmav_ref_reinmav")
+    old = sys.dont_write_bytecode
+    sys.dont_write_bytecode = True
+    try:
+        exec(compile(src, path, "exec"), mod.__dict__)
+    finally:
+        sys.dont_write_bytecode = old
+    mod.print = lambda *a, **k: None
+    _CACHE["reinmav"] = mod.ReinmavEnv
+    return mod.ReinmavEnv
+
+
+class RefReinmav:
+    """Driver around one reference ReinmavEnv object (state: 13 floats + the env's own clock t)."""
+
+    def __init__(self):
+        warnings.simplefilter("ignore")
+        self.env = load_reinmav_class()()
+
+    def set(self, state, t):
+        self.env.state = np.array(state, dtype=np.float64)
+        self.env.t = float(t)
+
+    def step(self):
+        s, r, d, _ = self.env.step()
+        return np.asarray(s, dtype=np.float64).ravel(), float(r), bool(d), float(self.env.t)
+
+    def substep_derivative(self, state, t):
+        return np.asarray(self.env.quad_eq_of_motion1(np.array(state, dtype=np.float64), float(t)), dtype=np.float64).ravel()
+
+    def force_moment(self, state, t):
+        qd = self.env.stateToQd(np.array(state, dtype=np.float64))
+        F, M = self.env.controller(float(t), qd, self.env.trj_gen(float(t)))
+        return np.array([float(np.asarray(F).ravel()[0])] + [float(m) for m in M])
+
+
 def _flat(x) -> np.ndarray:
     return np.array([float(np.asarray(e).reshape(())) for e in x], dtype=np.float64)
 

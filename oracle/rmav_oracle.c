@@ -520,3 +520,167 @@ int64_t oracle_rollout_random(int kind, const oracle_params *p, int64_t n, int64
     if (n_done) *n_done += nd;
     return n * steps;
 }
+
+/* ================================================================================================
+ * ReinmavEnv  (reinmav_env.py)
+ * ================================================================================================ */
+void oracle_reinmav_default_params(oracle_reinmav_params *p) {
+    memset(p, 0, sizeof(*p));
+    p->arm_length = 0.0860; /* :55 */
+    p->mass = 0.1800;       /* :56 */
+    p->gravity = 9.8100;    /* :57 */
+    p->min_force = 0.0;     /* :58 */
+    p->max_force = 3.5316;  /* :59 */
+    const double I[3][3] = {{0.00025, 0, 2.55e-06}, {0, 0.000232, 0}, {2.55e-06, 0, 0.0003738}}; /* :60-62 */
+    memcpy(p->inertia, I, sizeof(I));
+    /* Inertia.getI() (:63): 3x3 inverse by cofactors */
+    double c00 = I[1][1] * I[2][2] - I[1][2] * I[2][1], c01 = I[1][2] * I[2][0] - I[1][0] * I[2][2],
+           c02 = I[1][0] * I[2][1] - I[1][1] * I[2][0];
+    double det = I[0][0] * c00 + I[0][1] * c01 + I[0][2] * c02;
+    p->inv_inertia[0][0] = c00 / det;
+    p->inv_inertia[0][1] = (I[0][2] * I[2][1] - I[0][1] * I[2][2]) / det;
+    p->inv_inertia[0][2] = (I[0][1] * I[1][2] - I[0][2] * I[1][1]) / det;
+    p->inv_inertia[1][0] = c01 / det;
+    p->inv_inertia[1][1] = (I[0][0] * I[2][2] - I[0][2] * I[2][0]) / det;
+    p->inv_inertia[1][2] = (I[0][2] * I[1][0] - I[0][0] * I[1][2]) / det;
+    p->inv_inertia[2][0] = c02 / det;
+    p->inv_inertia[2][1] = (I[0][1] * I[2][0] - I[0][0] * I[2][1]) / det;
+    p->inv_inertia[2][2] = (I[0][0] * I[1][1] - I[0][1] * I[1][0]) / det;
+    p->dt = 1.0 / 100;  /* :73 */
+    p->ds = 1.0 / 5000; /* :91 */
+    p->t_max = 4.0;     /* :129 */
+    const double kp[3] = {10, 10, 35}, kd[3] = {5, 5, 22}, kpr[3] = {100, 100, 100}, kdr[3] = {.1, .1, .1};
+    memcpy(p->kp, kp, sizeof(kp));
+    memcpy(p->kd, kd, sizeof(kd));
+    memcpy(p->kp_rot, kpr, sizeof(kpr));
+    memcpy(p->kd_rot, kdr, sizeof(kdr));
+}
+
+/* quat2mat (:267-290) */
+static void reinmav_quat2mat(const double q[4], double m[3][3]) {
+    double w = q[0], x = q[1], y = q[2], z = q[3];
+    double Nq = w * w + x * x + y * y + z * z;
+    if (!(Nq > 2.220446049250313e-16)) { /* np.where(Nq > eps, mat, eye) */
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) m[i][j] = (i == j);
+        return;
+    }
+    double s = 2.0 / Nq;
+    double X = x * s, Y = y * s, Z = z * s;
+    double wX = w * X, wY = w * Y, wZ = w * Z;
+    double xX = x * X, xY = x * Y, xZ = x * Z;
+    double yY = y * Y, yZ = y * Z, zZ = z * Z;
+    m[0][0] = 1.0 - (yY + zZ); m[0][1] = xY - wZ;         m[0][2] = xZ + wY;
+    m[1][0] = xY + wZ;         m[1][1] = 1.0 - (xX + zZ); m[1][2] = yZ - wX;
+    m[2][0] = xZ - wY;         m[2][1] = yZ + wX;         m[2][2] = 1.0 - (xX + yY);
+}
+
+/* trj_gen (:128-136) -> [pos x3, vel x3, acc x3, pos, vel] */
+static void reinmav_trj(const oracle_reinmav_params *p, double t, double d[11]) {
+    double tm = p->t_max;
+    t = fmax(0.0, fmin(t, tm));
+    t = t / tm;
+    double pos = 10.0 * pow(t, 3) - 15.0 * pow(t, 4) + 6.0 * pow(t, 5);
+    double vel = (30 / tm) * pow(t, 2) - (60 / tm) * pow(t, 3) + (30 / tm) * pow(t, 4);
+    double acc = (60 / (tm * tm)) * t - (180 / (tm * tm)) * pow(t, 2) + (120 / (tm * tm)) * pow(t, 3);
+    d[0] = d[1] = d[2] = pos;
+    d[3] = d[4] = d[5] = vel;
+    d[6] = d[7] = d[8] = acc;
+    d[9] = pos;
+    d[10] = vel;
+}
+
+void oracle_reinmav_controller(const oracle_reinmav_params *p, const double s[13], double t, double fm[4]) {
+    /* stateToQd (:292-304) + RotToRPY (:341-346) */
+    double R[3][3];
+    const double q[4] = {s[6], s[7], s[8], s[9]};
+    reinmav_quat2mat(q, R);
+    double phi = asin(R[1][2]);
+    double psi = atan2(-R[1][0] / cos(phi), R[1][1] / cos(phi));
+    double theta = atan2(-R[0][2] / cos(phi), R[2][2] / cos(phi));
+    double d[11];
+    reinmav_trj(p, t, d);
+    /* controller (:306-337) */
+    double ddr[3];
+    for (int i = 0; i < 3; ++i) {
+        double ep = d[i] - s[i], ev = d[3 + i] - s[3 + i];
+        ddr[i] = d[6 + i] + p->kd[i] * ev + p->kp[i] * ep;
+    }
+    double psi_des = d[9], dpsi_des = d[10];
+    double u1 = p->mass * (p->gravity + ddr[2]);
+    double phi_des = 1 / p->gravity * (ddr[0] * sin(psi_des) - ddr[1] * cos(psi_des));
+    double theta_des = 1 / p->gravity * (ddr[0] * cos(psi_des) + ddr[1] * sin(psi_des));
+    fm[0] = u1;
+    fm[1] = p->kp_rot[0] * (phi_des - phi) - p->kd_rot[0] * s[10];
+    fm[2] = p->kp_rot[1] * (theta_des - theta) - p->kd_rot[1] * s[11];
+    fm[3] = p->kp_rot[2] * (psi_des - psi) + p->kd_rot[2] * (dpsi_des - s[12]);
+}
+
+void oracle_reinmav_derivative(const oracle_reinmav_params *p, const double s[13], const double fm[4],
+                               double sdot[13]) {
+    const double L = p->arm_length;
+    /* motor mixing (:206-216) */
+    const double A[4][3] = {{0.25, 0, -0.5 / L}, {0.25, 0.5 / L, 0.}, {0.25, 0, 0.5 / L}, {0.25, -0.5 / L, 0}};
+    double T[4];
+    for (int i = 0; i < 4; ++i) {
+        double v = A[i][0] * fm[0] + A[i][1] * fm[1] + A[i][2] * fm[2];
+        T[i] = fmax(fmin(v, p->max_force / 4.0), p->min_force / 4.0);
+    }
+    double force = 1.0 * T[0] + 1.0 * T[1] + 1.0 * T[2] + 1.0 * T[3];
+    double mom[3] = {0.0 * T[0] + L * T[1] + 0.0 * T[2] + (-L) * T[3], (-L) * T[0] + 0.0 * T[1] + L * T[2] + 0. * T[3],
+                     fm[3]};
+    /* :233-241 */
+    const double q[4] = {s[6], s[7], s[8], s[9]};
+    double bRw[3][3];
+    reinmav_quat2mat(q, bRw);
+    /* accel = 1/m * (wRb . (0,0,F) - (0,0,m g)),  wRb = bRw^T  (:240) */
+    double acc[3];
+    for (int i = 0; i < 3; ++i) {
+        double v = bRw[0][i] * 0.0 + bRw[1][i] * 0.0 + bRw[2][i] * force;
+        acc[i] = 1.0 / p->mass * (v - (i == 2 ? p->mass * p->gravity : 0.0));
+    }
+    /* qdot (:243-246) */
+    double pw = s[10], qw = s[11], rw = s[12];
+    double quaterror = 1 - (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const double Om[4][4] = {{0, -pw, -qw, -rw}, {pw, 0, -rw, qw}, {qw, rw, 0, -pw}, {rw, -qw, pw, 0}};
+    double qdot[4];
+    for (int i = 0; i < 4; ++i) {
+        double v = 0;
+        for (int j = 0; j < 4; ++j) v += (-1.0 / 2 * Om[i][j]) * q[j];
+        qdot[i] = v + 2.0 * quaterror * q[i];
+    }
+    /* pqrdot = invI (M - w x (I w))  (:248-250) */
+    double Iw[3], w[3] = {pw, qw, rw}, tmp[3], rhs[3];
+    for (int i = 0; i < 3; ++i) Iw[i] = p->inertia[i][0] * w[0] + p->inertia[i][1] * w[1] + p->inertia[i][2] * w[2];
+    tmp[0] = w[1] * Iw[2] - w[2] * Iw[1];
+    tmp[1] = w[2] * Iw[0] - w[0] * Iw[2];
+    tmp[2] = w[0] * Iw[1] - w[1] * Iw[0];
+    for (int i = 0; i < 3; ++i) rhs[i] = mom[i] - tmp[i];
+    sdot[0] = s[3]; sdot[1] = s[4]; sdot[2] = s[5];
+    sdot[3] = acc[0]; sdot[4] = acc[1]; sdot[5] = acc[2];
+    for (int i = 0; i < 4; ++i) sdot[6 + i] = qdot[i];
+    for (int i = 0; i < 3; ++i)
+        sdot[10 + i] = p->inv_inertia[i][0] * rhs[0] + p->inv_inertia[i][1] * rhs[1] + p->inv_inertia[i][2] * rhs[2];
+}
+
+int oracle_reinmav_step(const oracle_reinmav_params *p, double s[13], double *t, const double *action,
+                        double *reward, int *done) {
+    /* np.arange(t, t+dt, ds): length ceil((stop-start)/step); values start + i*delta with
+     * delta = (start+step) - start  (NumPy's fill for doubles) */
+    const double start = *t, stop = *t + p->dt;
+    int n = (int)ceil((stop - start) / p->ds);
+    if (n < 0) n = 0;
+    const double delta = (start + p->ds) - start;
+    for (int i = 0; i < n; ++i) {
+        double ti = (i == 0) ? start : ((i == 1) ? start + p->ds : start + i * delta);
+        double fm[4], sdot[13];
+        if (action) memcpy(fm, action, sizeof(fm));
+        else oracle_reinmav_controller(p, s, ti, fm);
+        oracle_reinmav_derivative(p, s, fm, sdot);
+        for (int k = 0; k < 13; ++k) s[k] = s[k] + p->ds * sdot[k]; /* :98 */
+    }
+    *reward = 100.0 - 10.0; /* :111-116 */
+    *done = 1;              /* :110 */
+    *t = *t + p->dt;        /* :119 */
+    return n;
+}

@@ -90,6 +90,28 @@ int64_t oracle_rollout_random(int kind, const oracle_params *p, int64_t n, int64
                               int32_t *sbd, uint32_t *episode, uint64_t t0, double *ret_sum,
                               int64_t *n_done);
 
+/* ---- ReinmavEnv (reinmav_env.py): 13-state rigid body, built-in PD controller + min-jerk trajectory ---- */
+typedef struct oracle_reinmav_params {
+    double arm_length, mass, gravity, min_force, max_force; /* reinmav_env.py:55-59 */
+    double inertia[3][3], inv_inertia[3][3];                /* :60-63 */
+    double dt, ds, t_max;                                   /* :73, :91, :129 */
+    double kp[3], kd[3], kp_rot[3], kd_rot[3];              /* :312-315 */
+} oracle_reinmav_params;
+void oracle_reinmav_default_params(oracle_reinmav_params *p);
+/* state order (reinmav_env.py:79): x y z dx dy dz qw qx qy qz p q r */
+/* trj_gen + stateToQd + controller (reinmav_env.py:128-136, 292-337): fm = (F, Mx, My, Mz) */
+void oracle_reinmav_controller(const oracle_reinmav_params *p, const double s[13], double t, double fm[4]);
+/* quad_eq_of_motion2 (reinmav_env.py:203-264): motor mixing + clamp, rigid-body derivative */
+void oracle_reinmav_derivative(const oracle_reinmav_params *p, const double s[13], const double fm[4],
+                               double sdot[13]);
+/* step() (reinmav_env.py:99-126) = myODE (:90-98): Euler sub-steps of ds over np.arange(t, t+dt, ds)
+ * (50 or 51 of them, decided by fp64 rounding of t), then t += dt.  action == NULL: the built-in
+ * controller is evaluated at every sub-step like the reference; otherwise (F, Mx, My, Mz) is held over the
+ * step (an extension: the reference has no action input).  reward is the reference's constant 90.0 and
+ * done is always 1.  Returns the number of sub-steps taken. */
+int oracle_reinmav_step(const oracle_reinmav_params *p, double s[13], double *t, const double *action,
+                        double *reward, int *done);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,8 +38,9 @@ int fail(int code, const char *fmt, ...) {
     } while (0)
 
 constexpr uint32_t kMagic = 0x524d4156u;  // 'RMAV'
-constexpr int kStateDim[4] = {5, 9, 10, 16};
-constexpr int kActionDim[4] = {2, 2, 4, 4};
+constexpr int kNumKinds = 5;
+constexpr int kStateDim[kNumKinds] = {5, 9, 10, 16, 13};
+constexpr int kActionDim[kNumKinds] = {2, 2, 4, 4, 4};
 
 }  // namespace
 
@@ -62,6 +63,7 @@ struct rmav_env_s {
     float *ep_ret, *last_ret;
     int32_t *ep_len, *last_len;
     Totals *totals;
+    double *env_time;  // RMAV_REINMAV only
     // scratch for host-pointer calls and layout conversion (grown on demand)
     void *scratch;
     size_t scratch_bytes;
@@ -127,8 +129,7 @@ int ensure_scratch(rmav_handle h, size_t bytes) {
 
 template <int K, int MODE>
 int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
-    using R = typename Env<K>::R;
-    const ParamsT<R> p = derive<R>(h->params);
+    const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     const size_t lds = (MODE == ACT_POLICY) ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL : 0;
     hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
@@ -152,6 +153,7 @@ int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
     case RMAV_QUAD2D_SL: return launch_rollout_k<QUAD2D_SL>(h, mode, a);
     case RMAV_QUAD3D: return launch_rollout_k<QUAD3D>(h, mode, a);
     case RMAV_QUAD3D_SL: return launch_rollout_k<QUAD3D_SL>(h, mode, a);
+    case RMAV_REINMAV: return launch_rollout_k<REINMAV>(h, mode, a);
     }
     return fail(RMAV_ERR_INVALID, "bad kind");
 }
@@ -168,6 +170,7 @@ RolloutArgs base_args(rmav_handle h) {
     a.last_ret = h->last_ret;
     a.last_len = h->last_len;
     a.totals = h->totals;
+    a.env_time = h->env_time;
     a.seed = h->seed;
     a.env_base = h->env_base;
     a.t0 = h->t;
@@ -188,6 +191,7 @@ int launch_reset(rmav_handle h, float *obs_dev, int layout) {
     case RMAV_QUAD2D_SL: RMAV_RESET_CASE(QUAD2D_SL); break;
     case RMAV_QUAD3D: RMAV_RESET_CASE(QUAD3D); break;
     case RMAV_QUAD3D_SL: RMAV_RESET_CASE(QUAD3D_SL); break;
+    case RMAV_REINMAV: RMAV_RESET_CASE(REINMAV); break;
     }
 #undef RMAV_RESET_CASE
     HIP_TRY(hipGetLastError());
@@ -205,6 +209,10 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
     case RMAV_QUAD2D_SL: RMAV_CTRL_CASE(QUAD2D_SL); break;
     case RMAV_QUAD3D: RMAV_CTRL_CASE(QUAD3D); break;
     case RMAV_QUAD3D_SL: RMAV_CTRL_CASE(QUAD3D_SL); break;
+    case RMAV_REINMAV:
+        hipLaunchKernelGGL(k_control_reinmav, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,
+                           h->env_time, h->n, act_dev, fl, derive_reinmav(h->params));
+        break;
     }
 #undef RMAV_CTRL_CASE
     HIP_TRY(hipGetLastError());
@@ -241,7 +249,7 @@ template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t cou
 
 void free_all(rmav_handle h) {
     void *ptrs[] = {h->state, h->sbd, h->reset_cnt, h->ep_ret, h->last_ret, h->ep_len, h->last_len,
-                    h->totals, h->scratch};
+                    h->totals, h->env_time, h->scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -267,17 +275,17 @@ int rmav_device_count(void) {
     return n < 0 ? 0 : n;
 }
 
-int rmav_state_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : kStateDim[kind]; }
-int rmav_action_dim(int kind) { return (kind < 0 || kind > 3) ? -1 : kActionDim[kind]; }
+int rmav_state_dim(int kind) { return (kind < 0 || kind >= kNumKinds) ? -1 : kStateDim[kind]; }
+int rmav_action_dim(int kind) { return (kind < 0 || kind >= kNumKinds) ? -1 : kActionDim[kind]; }
 
 int rmav_algorithmic_bytes(int kind) {
-    if (kind < 0 || kind > 3) return -1;
+    if (kind < 0 || kind >= kNumKinds) return -1;
     // read state + read action + write state + write reward (f32) + write done (u8)
     return 4 * (2 * kStateDim[kind] + kActionDim[kind] + 1) + 1;
 }
 
 int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
-    if (kind < 0 || kind > 3) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (kind < 0 || kind >= kNumKinds) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
     if (!p) return fail(RMAV_ERR_INVALID, "out is NULL");
     if (reading_2d != 0 && reading_2d != 'A' && reading_2d != 'B')
         return fail(RMAV_ERR_INVALID, "reading_2d must be 0, 'A' or 'B'");
@@ -319,6 +327,15 @@ int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
         p->ref_pos[2] = 1.0;
         p->tau = 0.3;
         break;
+    case RMAV_REINMAV:       // reinmav_env.py:55-73; only mass, g and dt are read from this struct
+        p->mass = 0.1800;
+        p->load_mass = 0.0;
+        p->g = 9.8100;
+        p->dt = 1.0 / 100;
+        p->tau = 1.0;        // unused (keeps check_params happy)
+        p->act_lo = 0.0;     // RMAV_ACT_RANDOM range for (F, Mx, My, Mz): [0, max_force)
+        p->act_hi = 3.5316;
+        break;
     }
     return RMAV_OK;
 }
@@ -327,7 +344,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
                 uint64_t env_id_base, uint32_t flags, const rmav_params *params, void *hip_stream) {
     if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < 0 || kind > 3) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (kind < 0 || kind >= kNumKinds) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
     if (n_envs <= 0 || n_envs > ((int64_t)1 << 25))  // 32-bit buffer offsets, see rmav_kernels.hpp
         return fail(RMAV_ERR_INVALID, "n_envs out of range: %lld", (long long)n_envs);
     if (flags & ~(RMAV_F_AUTO_RESET | RMAV_F_TRACK_EPISODES))
@@ -371,6 +388,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
               hipMalloc((void **)&h->sbd, n * sizeof(int32_t)) == hipSuccess &&
               hipMalloc((void **)&h->reset_cnt, n * sizeof(uint32_t)) == hipSuccess &&
               hipMalloc((void **)&h->totals, n_waves(n_envs) * sizeof(Totals)) == hipSuccess;
+    if (ok && kind == RMAV_REINMAV) ok = hipMalloc((void **)&h->env_time, n * sizeof(double)) == hipSuccess;
     if (ok && (flags & RMAV_F_TRACK_EPISODES)) {
         ok = hipMalloc((void **)&h->ep_ret, n * sizeof(float)) == hipSuccess &&
              hipMalloc((void **)&h->last_ret, n * sizeof(float)) == hipSuccess &&
@@ -395,8 +413,20 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         free_all(h);
         return fail(RMAV_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
-    // the reference constructors call seed() then reset()  (quadrotor3d.py:73-74)
-    if (int rc = launch_reset(h, nullptr, RMAV_SOA)) {
+    if (kind == RMAV_REINMAV) {
+        // ReinmavEnv.__init__ (reinmav_env.py:79-81): state = (0,0,0, 0,0,0, 1,0,0,0, 0,0,0), t = 0; no RNG
+        const float one = 1.0f;
+        uint32_t one_bits;
+        memcpy(&one_bits, &one, 4);
+        e = hipMemsetAsync(h->state, 0, n * nS * sizeof(float), h->stream);
+        if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(h->state + 6 * n), (int)one_bits, n, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->env_time, 0, n * sizeof(double), h->stream);
+        if (e != hipSuccess) {
+            free_all(h);
+            return fail(RMAV_ERR_HIP, "initial state failed: %s", hipGetErrorString(e));
+        }
+    } else if (int rc = launch_reset(h, nullptr, RMAV_SOA)) {
+        // the reference constructors call seed() then reset()  (quadrotor3d.py:73-74)
         free_all(h);
         return rc;
     }
@@ -560,6 +590,7 @@ int64_t rmav_policy_weight_count(int kind) {
     case RMAV_QUAD2D_SL: return PolicyLayout<9>::TOTAL;
     case RMAV_QUAD3D: return PolicyLayout<10>::TOTAL;
     case RMAV_QUAD3D_SL: return PolicyLayout<16>::TOTAL;
+    case RMAV_REINMAV: return PolicyLayout<13>::TOTAL;
     }
     return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
 }
@@ -662,6 +693,19 @@ int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
     return copy_in(h, h->reset_cnt, in, (size_t)h->n, mem);
+}
+
+int rmav_get_time(rmav_handle h, double *out, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only RMAV_REINMAV envs carry their own clock");
+    return copy_out(h, (const double *)h->env_time, out, (size_t)h->n, mem);
+}
+int rmav_set_time(rmav_handle h, const double *in, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only RMAV_REINMAV envs carry their own clock");
+    return copy_in(h, h->env_time, in, (size_t)h->n, mem);
 }
 
 int rmav_get_step_count(rmav_handle h, uint64_t *out) {

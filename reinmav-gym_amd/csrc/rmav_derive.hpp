@@ -36,4 +36,44 @@ template <typename R> inline ParamsT<R> derive(const rmav_params &q) {
     return p;
 }
 
+// ReinmavEnv constants: mass / gravity / dt come from rmav_params, the rest are the reference's literals
+// (reinmav_env.py:55-63, :91, :129, :312-315).
+inline ReinmavP derive_reinmav(const rmav_params &q) {
+    ReinmavP p;
+    memset(&p, 0, sizeof(p));
+    p.arm_length = 0.0860;
+    p.mass = q.mass;
+    p.gravity = q.g;
+    p.min_force4 = 0.0 / 4.0;
+    p.max_force4 = 3.5316 / 4.0;
+    const double I[3][3] = {{0.00025, 0, 2.55e-06}, {0, 0.000232, 0}, {2.55e-06, 0, 0.0003738}};
+    memcpy(p.inertia, I, sizeof(I));
+    const double c00 = I[1][1] * I[2][2] - I[1][2] * I[2][1], c01 = I[1][2] * I[2][0] - I[1][0] * I[2][2],
+                 c02 = I[1][0] * I[2][1] - I[1][1] * I[2][0];
+    const double det = I[0][0] * c00 + I[0][1] * c01 + I[0][2] * c02;
+    p.inv_inertia[0][0] = c00 / det;
+    p.inv_inertia[0][1] = (I[0][2] * I[2][1] - I[0][1] * I[2][2]) / det;
+    p.inv_inertia[0][2] = (I[0][1] * I[1][2] - I[0][2] * I[1][1]) / det;
+    p.inv_inertia[1][0] = c01 / det;
+    p.inv_inertia[1][1] = (I[0][0] * I[2][2] - I[0][2] * I[2][0]) / det;
+    p.inv_inertia[1][2] = (I[0][2] * I[1][0] - I[0][0] * I[1][2]) / det;
+    p.inv_inertia[2][0] = c02 / det;
+    p.inv_inertia[2][1] = (I[0][1] * I[2][0] - I[0][0] * I[2][1]) / det;
+    p.inv_inertia[2][2] = (I[0][0] * I[1][1] - I[0][1] * I[1][0]) / det;
+    p.dt = q.dt;
+    p.ds = 1.0 / 5000;
+    p.t_max = 4.0;
+    const double kp[3] = {10, 10, 35}, kd[3] = {5, 5, 22}, kpr[3] = {100, 100, 100}, kdr[3] = {.1, .1, .1};
+    memcpy(p.kp, kp, sizeof(kp));
+    memcpy(p.kd, kd, sizeof(kd));
+    memcpy(p.kp_rot, kpr, sizeof(kpr));
+    memcpy(p.kd_rot, kdr, sizeof(kdr));
+    return p;
+}
+
+template <int K> inline typename Env<K>::P derive_env(const rmav_params &q) {
+    if constexpr (K == REINMAV) return derive_reinmav(q);
+    else return derive<typename Env<K>::R>(q);
+}
+
 }  // namespace rmav

@@ -55,6 +55,7 @@ struct RolloutArgs {
     uint32_t flags;
     float act_lo, act_hi;
     // ACT_POLICY only
+    double *env_time;       // REINMAV only: the env's own clock t [N] (fp64: it decides 50 vs 51 sub-steps)
     const float *policy_w;  // packed weights (rmav_policy.hpp layout), device memory
     float *logp_out;        // [n_steps][N]
     float *val_out;         // [n_steps + 1][N]
@@ -93,8 +94,7 @@ __device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t sof
 }
 
 template <int K, int MODE>
-__global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
-                                                    const ParamsT<typename Env<K>::R> p,
+__global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p,
                                                     const ParamsT<double> pc) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;  // local env index
@@ -137,6 +137,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
         const int32_t sb0 = sb;
         const uint32_t rc0 = rc;
         const uint64_t env_id = a.env_base + (uint64_t)li;
+        double tenv = 0.0;
+        if constexpr (K == REINMAV) tenv = a.env_time[li];
 
         // Spare reset state.  PMC counters (profiles/r01) show the fused kernel is instruction-issue bound
         // at C2: one wavefront per SIMD, ~4 cycles per instruction, SQ_ACTIVE_INST_ANY = 75 % of
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
         // falls back to drawing on demand.  Same counters, same bits either way.
         float spare[NS];
         bool have_spare = false;
-        if (auto_reset && a.n_steps >= 8) {
+        if (K != REINMAV && auto_reset && a.n_steps >= 8) {   // ReinmavEnv.reset() is a no-op (reinmav_env.py:348-351)
             reset_state<K>(a.seed, env_id, rc, spare);
             have_spare = true;
         }
@@ -212,8 +214,33 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                 act_in += (int64_t)NA * n;
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
+            } else if constexpr (K == REINMAV) {
+#pragma unroll
+                for (int c = 0; c < NA; ++c) act[c] = 0.0f;   // the built-in controller runs inside every sub-step
             } else {
                 env_control<K>(s, pc, act);
+            }
+
+            float dist = 0.0f;
+            bool done;
+            float r;
+            if constexpr (K == REINMAV) {
+                float fm0[4];
+                Env<K>::step(s, act, MODE == ACT_CONTROLLER, tenv, p, fm0);
+                if (MODE == ACT_CONTROLLER) {
+#pragma unroll
+                    for (int c = 0; c < NA; ++c) act[c] = fm0[c];   // reported action = command of sub-step 0
+                }
+                done = true;   // reinmav_env.py:110
+                r = 90.0f;     // reinmav_env.py:111-116: 100 - 10, every step
+            } else {
+                Env<K>::step(s, act, p, dist, done);
+                // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
+                r = -dist;
+                if (done) {
+                    r = (sb < 0) ? 1.0f : 0.0f;
+                    sb = (sb < 0) ? 0 : sb + 1;
+                }
             }
             if (act_out) {
                 if (aos) {
@@ -221,23 +248,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
 #pragma unroll
                     for (int c = 0; c < NA; ++c) dst[c] = act[c];
                 } else {
-                    const rsrc_t r = make_rsrc(act_out);
+                    const rsrc_t ra = make_rsrc(act_out);
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) buf_st(r, off, (uint32_t)c * col, act[c]);
+                    for (int c = 0; c < NA; ++c) buf_st(ra, off, (uint32_t)c * col, act[c]);
                 }
                 act_out += (int64_t)NA * n;
             }
 
-            float dist;
-            bool done;
-            Env<K>::step(s, act, p, dist, done);
-
-            // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
-            float r = -dist;
-            if (done) {
-                r = (sb < 0) ? 1.0f : 0.0f;
-                sb = (sb < 0) ? 0 : sb + 1;
-            }
             if (track) {
                 er += r;
                 el += 1;
@@ -251,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
                     el = 0;
                 }
             }
-            if (done && auto_reset) {
+            if (K != REINMAV && done && auto_reset) {
                 if (have_spare) {
 #pragma unroll
                     for (int c = 0; c < NS; ++c) s[c] = spare[c];
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a,
             buf_st(make_rsrc(a.ep_ret), off, 0, er);
             buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
         }
+        if constexpr (K == REINMAV) a.env_time[li] = tenv;
         if (sb != sb0) buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
         if (rc != rc0) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     }
@@ -329,10 +347,15 @@ __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint3
     if (i >= n) return;
     float s[NS];
     const uint32_t rc = reset_cnt[i];
-    reset_state<K>(seed, env_base + (uint64_t)i, rc, s);
-    reset_cnt[i] = rc + 1;
+    if constexpr (K == REINMAV) {   // ReinmavEnv.reset() returns the current state unchanged (reinmav_env.py:348-351)
 #pragma unroll
-    for (int c = 0; c < NS; ++c) state[(int64_t)c * n + i] = s[c];
+        for (int c = 0; c < NS; ++c) s[c] = state[(int64_t)c * n + i];
+    } else {
+        reset_state<K>(seed, env_base + (uint64_t)i, rc, s);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) state[(int64_t)c * n + i] = s[c];
+    }
+    reset_cnt[i] = rc + 1;
     if (flags & F_TRACK) {
         ep_ret[i] = 0.0f;
         ep_len[i] = 0;
@@ -365,6 +388,22 @@ __global__ __launch_bounds__(kBlock) void k_control(const float *state, int64_t 
     } else {
 #pragma unroll
         for (int c = 0; c < NA; ++c) act_out[(int64_t)c * n + i] = act[c];
+    }
+}
+
+// ReinmavEnv: the built-in controller's command (F, Mx, My, Mz) at the env's current (state, t)
+__global__ __launch_bounds__(kBlock) void k_control_reinmav(const float *state, const double *env_time, int64_t n,
+                                                            float *act_out, uint32_t flags, const ReinmavP p) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s[13], fm[4];
+#pragma unroll
+    for (int c = 0; c < 13; ++c) s[c] = state[(int64_t)c * n + i];
+    reinmav_controller(p, s, env_time[i], fm);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (flags & F_AOS) act_out[i * 4 + c] = (float)fm[c];
+        else act_out[(int64_t)c * n + i] = (float)fm[c];
     }
 }
 

@@ -28,13 +28,14 @@
 
 namespace rmav {
 
-enum : int { QUAD2D = 0, QUAD2D_SL = 1, QUAD3D = 2, QUAD3D_SL = 3 };
+enum : int { QUAD2D = 0, QUAD2D_SL = 1, QUAD3D = 2, QUAD3D_SL = 3, REINMAV = 4 };
 
 template <int K> struct Dims;
 template <> struct Dims<QUAD2D>    { static constexpr int NS = 5,  NA = 2; using real = float;  };
 template <> struct Dims<QUAD2D_SL> { static constexpr int NS = 9,  NA = 2; using real = double; };
 template <> struct Dims<QUAD3D>    { static constexpr int NS = 10, NA = 4; using real = float;  };
 template <> struct Dims<QUAD3D_SL> { static constexpr int NS = 16, NA = 4; using real = double; };
+template <> struct Dims<REINMAV>   { static constexpr int NS = 13, NA = 4; using real = double; };
 
 // ---- scalar helpers -----------------------------------------------------------------------------
 RMAV_HD float  rfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
@@ -159,6 +160,7 @@ template <int K> struct Env;
 // Quadrotor3D.step  quadrotor3d.py:81-124
 template <> struct Env<QUAD3D> {
     using R = float;
+    using P = ParamsT<R>;
     static RMAV_HD void step(float (&s)[10], const float (&a)[4], const ParamsT<R> &p, float &dist,
                              bool &done) {
         const R q[4] = {s[3], s[4], s[5], s[6]};
@@ -187,6 +189,7 @@ template <> struct Env<QUAD3D> {
 // Quadrotor3DSlungload.step  quadrotor3d_slungload.py:87-167
 template <> struct Env<QUAD3D_SL> {
     using R = double;
+    using P = ParamsT<R>;
     static RMAV_HD void step(float (&s)[16], const float (&a)[4], const ParamsT<R> &p, float &dist,
                              bool &done) {
         R pos[3] = {s[0], s[1], s[2]};
@@ -261,6 +264,7 @@ template <> struct Env<QUAD3D_SL> {
 // Quadrotor2D.step  quadrotor2d.py:74-113
 template <> struct Env<QUAD2D> {
     using R = float;
+    using P = ParamsT<R>;
     static RMAV_HD void step(float (&s)[5], const float (&a)[2], const ParamsT<R> &p, float &dist,
                              bool &done) {
         R thrust = p.thrust_scale * a[0];                         // :75
@@ -287,6 +291,7 @@ template <> struct Env<QUAD2D> {
 // Quadrotor2DSlungload.step  quadrotor2d_slungload.py:79-154  (velocity-first updates)
 template <> struct Env<QUAD2D_SL> {
     using R = double;
+    using P = ParamsT<R>;
     static RMAV_HD void step(float (&s)[9], const float (&a)[2], const ParamsT<R> &p, float &dist,
                              bool &done) {
         R pos[2] = {s[0], s[1]};
@@ -426,11 +431,147 @@ RMAV_HD void control_2d(const float (&s)[NS], const ParamsT<double> &p, float (&
     a[0] = (float)(p.mass * rsqrt_ieee(rfma(ax, ax, ay * ay)));   // :134
 }
 
+// ================================================================================================
+// ReinmavEnv  (reinmav_env.py): 13-state rigid body  [x y z dx dy dz qw qx qy qz p q r]  (:79),
+// thrust + body torques -> motor mixing with clamp -> linear / angular acceleration (:203-264), a
+// built-in PD position/attitude controller tracking a min-jerk trajectory (:128-136, :306-337), 50-or-51
+// explicit-Euler sub-steps of 1/5000 s per step (:90-98).  The reference's step() takes no action.
+// fp64 arithmetic on fp32 state: the attitude loop has gain kp_rot/I ~ 4e5 1/s^2, so fp32 rounding of the
+// Euler angles would show up as 1e-4 rad/s in the body rates.
+// ================================================================================================
+struct ReinmavP {
+    double arm_length, mass, gravity, min_force4, max_force4;  // force limits per rotor (:59, :212)
+    double inertia[3][3], inv_inertia[3][3];
+    double dt, ds, t_max;
+    double kp[3], kd[3], kp_rot[3], kd_rot[3];
+};
+
+RMAV_HD void reinmav_quat2mat(const double (&q)[4], double (&m)[3][3]) {   // quat2mat :267-290
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double Nq = rfma(w, w, rfma(x, x, rfma(y, y, z * z)));
+    if (!(Nq > 2.220446049250313e-16)) {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) m[i][j] = (i == j) ? 1.0 : 0.0;
+        return;
+    }
+    const double sc = 2.0 / Nq;
+    const double X = x * sc, Y = y * sc, Z = z * sc;
+    const double wX = w * X, wY = w * Y, wZ = w * Z;
+    const double xX = x * X, xY = x * Y, xZ = x * Z;
+    const double yY = y * Y, yZ = y * Z, zZ = z * Z;
+    m[0][0] = 1.0 - (yY + zZ); m[0][1] = xY - wZ;         m[0][2] = xZ + wY;
+    m[1][0] = xY + wZ;         m[1][1] = 1.0 - (xX + zZ); m[1][2] = yZ - wX;
+    m[2][0] = xZ - wY;         m[2][1] = yZ + wX;         m[2][2] = 1.0 - (xX + yY);
+}
+
+// trj_gen (:128-136) + stateToQd / RotToRPY (:292-304, :341-346) + controller (:306-337) -> (F, Mx, My, Mz)
+RMAV_HD void reinmav_controller(const ReinmavP &p, const double (&s)[13], double t, double (&fm)[4]) {
+    double R[3][3];
+    const double q[4] = {s[6], s[7], s[8], s[9]};
+    reinmav_quat2mat(q, R);
+    const double phi = asin(R[1][2]);
+    const double cphi = cos(phi);
+    const double psi = atan2(-R[1][0] / cphi, R[1][1] / cphi);
+    const double theta = atan2(-R[0][2] / cphi, R[2][2] / cphi);
+    const double tm = p.t_max;
+    double u = t < tm ? t : tm;
+    u = (u > 0.0 ? u : 0.0) / tm;
+    const double u2 = u * u, u3 = u2 * u, u4 = u2 * u2, u5 = u4 * u;
+    const double pos = 10.0 * u3 - 15.0 * u4 + 6.0 * u5;
+    const double vel = (30 / tm) * u2 - (60 / tm) * u3 + (30 / tm) * u4;
+    const double acc = (60 / (tm * tm)) * u - (180 / (tm * tm)) * u2 + (120 / (tm * tm)) * u3;
+    double ddr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ddr[i] = acc + p.kd[i] * (vel - s[3 + i]) + p.kp[i] * (pos - s[i]);
+    const double psi_des = pos, dpsi_des = vel;
+    double sp, cp;
+    sincos(psi_des, &sp, &cp);
+    const double phi_des = 1 / p.gravity * (ddr[0] * sp - ddr[1] * cp);
+    const double theta_des = 1 / p.gravity * (ddr[0] * cp + ddr[1] * sp);
+    fm[0] = p.mass * (p.gravity + ddr[2]);
+    fm[1] = p.kp_rot[0] * (phi_des - phi) - p.kd_rot[0] * s[10];
+    fm[2] = p.kp_rot[1] * (theta_des - theta) - p.kd_rot[1] * s[11];
+    fm[3] = p.kp_rot[2] * (psi_des - psi) + p.kd_rot[2] * (dpsi_des - s[12]);
+}
+
+// quad_eq_of_motion2 (:203-264): one explicit Euler sub-step  s <- s + ds * f(s, F, M)
+RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&fm)[4]) {
+    const double L = p.arm_length, k = 0.5 / L;
+    double T[4] = {0.25 * fm[0] - k * fm[2], 0.25 * fm[0] + k * fm[1], 0.25 * fm[0] + k * fm[2], 0.25 * fm[0] - k * fm[1]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // np.maximum(np.minimum(T, max/4), min/4)
+        T[i] = T[i] < p.max_force4 ? T[i] : p.max_force4;
+        T[i] = T[i] > p.min_force4 ? T[i] : p.min_force4;
+    }
+    const double force = T[0] + T[1] + T[2] + T[3];
+    const double mom[3] = {L * T[1] - L * T[3], L * T[2] - L * T[0], fm[3]};
+    const double q[4] = {s[6], s[7], s[8], s[9]};
+    double bRw[3][3];
+    reinmav_quat2mat(q, bRw);
+    const double im = 1.0 / p.mass;
+    const double acc[3] = {im * (bRw[2][0] * force), im * (bRw[2][1] * force), im * (bRw[2][2] * force - p.mass * p.gravity)};
+    const double pw = s[10], qw = s[11], rw = s[12];
+    const double qerr = 2.0 * (1.0 - (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]));   // K_quat = 2 (:242)
+    const double qd[4] = {-0.5 * (-pw * q[1] - qw * q[2] - rw * q[3]) + qerr * q[0],
+                          -0.5 * (pw * q[0] - rw * q[2] + qw * q[3]) + qerr * q[1],
+                          -0.5 * (qw * q[0] + rw * q[1] - pw * q[3]) + qerr * q[2],
+                          -0.5 * (rw * q[0] - qw * q[1] + pw * q[2]) + qerr * q[3]};
+    const double w[3] = {pw, qw, rw};
+    double Iw[3], rhs[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Iw[i] = p.inertia[i][0] * w[0] + p.inertia[i][1] * w[1] + p.inertia[i][2] * w[2];
+    rhs[0] = mom[0] - (w[1] * Iw[2] - w[2] * Iw[1]);
+    rhs[1] = mom[1] - (w[2] * Iw[0] - w[0] * Iw[2]);
+    rhs[2] = mom[2] - (w[0] * Iw[1] - w[1] * Iw[0]);
+    const double ds = p.ds;
+    const double v0 = s[3], v1 = s[4], v2 = s[5];
+    s[0] = rfma(ds, v0, s[0]); s[1] = rfma(ds, v1, s[1]); s[2] = rfma(ds, v2, s[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s[3 + i] = rfma(ds, acc[i], s[3 + i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[6 + i] = rfma(ds, qd[i], s[6 + i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        s[10 + i] = rfma(ds, p.inv_inertia[i][0] * rhs[0] + p.inv_inertia[i][1] * rhs[1] + p.inv_inertia[i][2] * rhs[2], s[10 + i]);
+}
+
+template <> struct Env<REINMAV> {
+    using R = double;
+    using P = ReinmavP;
+    // step() :99-126.  use_controller: evaluate the built-in controller at every sub-step (the reference);
+    // otherwise hold the caller's (F, Mx, My, Mz) over the step.  fm0 returns the command of sub-step 0.
+    static RMAV_HD void step(float (&sf)[13], const float (&a)[4], bool use_controller, double &t, const ReinmavP &p,
+                             float (&fm0)[4]) {
+        double s[13];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s[i] = sf[i];
+        // np.arange(t, t+dt, ds): ceil((stop-start)/step) values  start + i*delta, delta = (start+step)-start
+        const double start = t, stop = t + p.dt;
+        int n = (int)ceil((stop - start) / p.ds);
+        const double delta = (start + p.ds) - start;
+        double fm[4] = {a[0], a[1], a[2], a[3]};
+        for (int i = 0; i < n; ++i) {
+            if (use_controller) {
+                const double ti = (i == 0) ? start : ((i == 1) ? start + p.ds : start + i * delta);
+                reinmav_controller(p, s, ti, fm);
+            }
+            if (i == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fm0[c] = (float)fm[c];
+            }
+            reinmav_substep(p, s, fm);
+        }
+        t = t + p.dt;   // :119
+#pragma unroll
+        for (int i = 0; i < 13; ++i) sf[i] = (float)s[i];
+    }
+};
+
 template <int K>
 RMAV_HD void env_control(const float (&s)[Dims<K>::NS], const ParamsT<double> &p,
                          float (&a)[Dims<K>::NA]) {
     if constexpr (K == QUAD3D || K == QUAD3D_SL) control_3d<Dims<K>::NS>(s, p, a);
-    else control_2d<Dims<K>::NS>(s, p, a);
+    else if constexpr (K == QUAD2D || K == QUAD2D_SL) control_2d<Dims<K>::NS>(s, p, a);
 }
 
 }  // namespace rmav

@@ -12,11 +12,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librmav.so")
 
 # enums of include/rmav.h
-QUAD2D, QUAD2D_SL, QUAD3D, QUAD3D_SL = 0, 1, 2, 3
-KIND_NAMES = {QUAD2D: "quad2d", QUAD2D_SL: "quad2d_sl", QUAD3D: "quad3d", QUAD3D_SL: "quad3d_sl"}
+QUAD2D, QUAD2D_SL, QUAD3D, QUAD3D_SL, REINMAV = 0, 1, 2, 3, 4
+KIND_NAMES = {QUAD2D: "quad2d", QUAD2D_SL: "quad2d_sl", QUAD3D: "quad3d", QUAD3D_SL: "quad3d_sl", REINMAV: "reinmav"}
 KIND_BY_NAME = {v: k for k, v in KIND_NAMES.items()}
-STATE_DIM = {QUAD2D: 5, QUAD2D_SL: 9, QUAD3D: 10, QUAD3D_SL: 16}
-ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4}
+STATE_DIM = {QUAD2D: 5, QUAD2D_SL: 9, QUAD3D: 10, QUAD3D_SL: 16, REINMAV: 13}
+ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4, REINMAV: 4}
 HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
 ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY = 0, 1, 2, 3
@@ -90,6 +90,8 @@ PROTOTYPES = {
     "rmav_set_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),
     "rmav_get_reset_counts": (C.c_int, [C.c_void_p, _vp, C.c_int]),
     "rmav_set_reset_counts": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_get_time": (C.c_int, [C.c_void_p, _vp, C.c_int]),
+    "rmav_set_time": (C.c_int, [C.c_void_p, _vp, C.c_int]),
     "rmav_get_step_count": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "rmav_set_step_count": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rmav_episode_totals": (C.c_int, [C.c_void_p, C.POINTER(EpTotals), C.c_int]),

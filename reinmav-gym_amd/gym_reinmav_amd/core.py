@@ -229,6 +229,16 @@ class BatchedQuadrotor:
         assert rc.shape == (self.num_envs,)
         A.check(self._lib.rmav_set_reset_counts(self._h, self._ptr(rc), A.HOST))
 
+    def get_time(self) -> np.ndarray:
+        """'reinmav' envs only: each env's own clock t (float64)."""
+        out = np.empty(self.num_envs, dtype=np.float64)
+        A.check(self._lib.rmav_get_time(self._h, self._ptr(out), A.HOST))
+        return out
+
+    def set_time(self, t):
+        t = np.ascontiguousarray(np.broadcast_to(np.asarray(t, dtype=np.float64), (self.num_envs,)))
+        A.check(self._lib.rmav_set_time(self._h, self._ptr(t), A.HOST))
+
     # ---- episode statistics ------------------------------------------------------------------------------
     def episode_totals(self, clear: bool = False) -> dict:
         t = A.EpTotals()

@@ -1,9 +1,10 @@
 """Gym registry glue: the reference registers its envs in ``gym_reinmav/__init__.py:3-26``; the same
-four native ids are registered here (under gym or gymnasium when importable) and are always
+five native ids are registered here (under gym or gymnasium when importable) and are always
 available through :func:`make`."""
 from __future__ import annotations
 
 ENTRY_POINTS = {
+    "reinmav-v0": "gym_reinmav_amd.envs.native:ReinmavEnv",
     "quadrotor2d-v0": "gym_reinmav_amd.envs.native:Quadrotor2D",
     "quadrotor2d-slungload-v0": "gym_reinmav_amd.envs.native:Quadrotor2DSlungload",
     "quadrotor3d-v0": "gym_reinmav_amd.envs.native:Quadrotor3D",

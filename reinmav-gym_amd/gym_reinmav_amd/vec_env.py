@@ -16,12 +16,13 @@ from .core import BatchedQuadrotor, torch
 from .spaces import Box
 
 ENV_IDS = {
+    "reinmav-v0": "reinmav",
     "quadrotor2d-v0": "quad2d",
     "quadrotor2d-slungload-v0": "quad2d_sl",
     "quadrotor3d-v0": "quad3d",
     "quadrotor3d-slungload-v0": "quad3d_sl",
 }
-_ACTION_BOX = {"quad2d": (-10.0, 10.0), "quad2d_sl": (-10.0, 10.0), "quad3d": (0.0, 10.0), "quad3d_sl": (-10.0, 10.0)}
+_ACTION_BOX = {"reinmav": (0.0, 3.5316), "quad2d": (-10.0, 10.0), "quad2d_sl": (-10.0, 10.0), "quad3d": (0.0, 10.0), "quad3d_sl": (-10.0, 10.0)}
 
 
 class QuadrotorVecEnv:

@@ -189,8 +189,44 @@ def run_traj(kind, seeds=(0, 1, 2, 3), steps=400, reading="B"):
     return np.array(TS), np.array(TA), np.array(TS2), np.array(TR), np.array(TD, dtype=bool)
 
 
+def make_reinmav():
+    """reinmav_env.py: the reference's own 400-step run (test/test_reinmav.py:16-22) plus perturbed single steps.
+    Keys: run_s [400,13], run_t [400] (state / clock before each step), run_s2 [400,13], run_t2 [400];
+    step_s [m,13], step_t [m], step_s2, step_t2; ctrl_s, ctrl_t, ctrl_fm [m,4] (built-in controller output)."""
+    env = rh.RefReinmav()
+    S, T, S2, T2 = [], [], [], []
+    for _ in range(400):
+        S.append(np.array(env.env.state, dtype=np.float64).ravel())
+        T.append(env.env.t)
+        s2, r, d, t2 = env.step()
+        assert r == 90.0 and d is True
+        S2.append(s2)
+        T2.append(t2)
+    out = {"run_s": np.array(S), "run_t": np.array(T), "run_s2": np.array(S2), "run_t2": np.array(T2)}
+    rng = np.random.RandomState(15)
+    ps, pt = [], []
+    for i in range(192):
+        k = rng.randint(0, 400)
+        s = out["run_s"][k] + rng.normal(scale=0.02 if i % 2 else 0.002, size=13)
+        ps.append(f32r(s))
+        pt.append(float(rng.uniform(0, 4.5)) if i % 3 else float(out["run_t"][k]))
+    ps, pt = np.array(ps), np.array(pt)
+    ps2, pt2, fm = [], [], []
+    for s, t in zip(ps, pt):
+        fm.append(env.force_moment(s, t))
+        env.set(s, t)
+        s2, _, _, t2 = env.step()
+        ps2.append(s2)
+        pt2.append(t2)
+    out.update({"step_s": ps, "step_t": pt, "step_s2": np.array(ps2), "step_t2": np.array(pt2), "ctrl_fm": np.array(fm)})
+    path = os.path.join(HERE, "reinmav.npz")
+    np.savez_compressed(path, **out)
+    print("reinmav", {k: v.shape for k, v in out.items()}, os.path.getsize(path), "bytes")
+
+
 def main():
     assert rh.available(), "the reference tree is required to regenerate golden vectors"
+    make_reinmav()
     e_rot, e_mul = rh.selfcheck_quaternion()
     assert e_rot < 1e-14 and e_mul < 1e-14, (e_rot, e_mul)
     for kind in rh.KINDS:

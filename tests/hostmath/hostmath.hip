@@ -76,6 +76,19 @@ int hm_control(int kind, const rmav_params *q, int64_t n, const float *s, float 
     }
     return 0;
 }
+// ReinmavEnv: n envs, s [n][13] in/out, t [n] in/out, a [n][4] or NULL (-> built-in controller), fm0 [n][4] out
+int hm_reinmav_step(const rmav_params *q, int64_t n, float *s, double *t, const float *a, float *fm0) {
+    const ReinmavP p = derive_reinmav(*q);
+    for (int64_t e = 0; e < n; ++e) {
+        float ss[13], aa[4] = {0, 0, 0, 0}, f0[4];
+        for (int i = 0; i < 13; ++i) ss[i] = s[e * 13 + i];
+        if (a) for (int i = 0; i < 4; ++i) aa[i] = a[e * 4 + i];
+        Env<REINMAV>::step(ss, aa, a == nullptr, t[e], p, f0);
+        for (int i = 0; i < 13; ++i) s[e * 13 + i] = ss[i];
+        for (int i = 0; i < 4; ++i) fm0[e * 4 + i] = f0[i];
+    }
+    return 0;
+}
 int hm_reset_state(int kind, uint64_t seed, uint64_t env, uint32_t idx, float *s) {
     switch (kind) {
     case QUAD2D: reset_k<QUAD2D>(seed, env, idx, s); break;

@@ -31,9 +31,9 @@ def test_library_level_queries(built):
 
     L = A.lib()
     assert L.rmav_version() == 100
-    assert [L.rmav_state_dim(k) for k in range(4)] == [5, 9, 10, 16]
-    assert [L.rmav_action_dim(k) for k in range(4)] == [2, 2, 4, 4]
-    assert [L.rmav_algorithmic_bytes(k) for k in range(4)] == [53, 85, 101, 149]
+    assert [L.rmav_state_dim(k) for k in range(5)] == [5, 9, 10, 16, 13]
+    assert [L.rmav_action_dim(k) for k in range(5)] == [2, 2, 4, 4, 4]
+    assert [L.rmav_algorithmic_bytes(k) for k in range(5)] == [53, 85, 101, 149, 125]
     assert L.rmav_state_dim(7) == -1
     p = A.Params()
     assert L.rmav_default_params(9, 0, C.byref(p)) == A.ERR_INVALID
@@ -47,6 +47,11 @@ def test_default_params_match_oracle_defaults(built):
     from gym_reinmav_amd import _abi as A
 
     for kind, name in A.KIND_NAMES.items():
+        if name == "reinmav":
+            q = O.reinmav_params()
+            p = A.default_params(kind)
+            assert (p.mass, p.g, p.dt) == (q.mass, q.gravity, q.dt)
+            continue
         for reading in ("A", "B"):
             p, q = A.default_params(kind, reading), O.default_params(name, reading)
             for f in ("mass", "load_mass", "dt", "g", "tether_length", "pos_limit", "vel_limit", "thrust_scale",

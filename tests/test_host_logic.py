@@ -22,11 +22,12 @@ def test_shard_range_partitions_exactly():
 def test_registry_ids_match_reference():
     import gym_reinmav_amd as g
 
+    # the five native ids of gym_reinmav/__init__.py:3-26 (the three MuJoCo ids are out of scope)
     assert sorted(g.ENTRY_POINTS) == ["quadrotor2d-slungload-v0", "quadrotor2d-v0", "quadrotor3d-slungload-v0",
-                                      "quadrotor3d-v0"]
+                                      "quadrotor3d-v0", "reinmav-v0"]
     assert g.ENV_IDS["quadrotor3d-v0"] == "quad3d"
     with pytest.raises(KeyError):
-        g.make("reinmav-v0")  # out of scope, not silently mapped to something else
+        g.make("MujocoQuadForce-v0")  # out of scope, not silently mapped to something else
 
 
 def test_box_space():
