@@ -157,6 +157,11 @@ int rmav_set_params(rmav_handle h, const rmav_params *in);
  * rmav_rollout launches (mem = RMAV_DEVICE: no allocation, no synchronisation) into a hipGraph on its
  * capture stream. */
 int rmav_set_stream(rmav_handle h, void *hip_stream);
+/* Per-env (domain-randomised) physical constants.  The reference hard-codes one value per class
+ * (quadrotor3d_slungload.py:45-59); RL users randomise them per env.  values: N floats (one per env)
+ * or NULL to go back to the shared value of rmav_params.  Quadrotor kinds only. */
+enum rmav_env_param { RMAV_PARAM_MASS = 0, RMAV_PARAM_LOAD_MASS = 1, RMAV_PARAM_TETHER_LENGTH = 2 };
+int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem);
 int64_t rmav_num_envs(rmav_handle h); /* < 0 on a bad handle */
 int rmav_sync(rmav_handle h);         /* waits for everything enqueued on the handle's stream */
 

@@ -64,6 +64,7 @@ struct rmav_env_s {
     int32_t *ep_len, *last_len;
     Totals *totals;
     double *env_time;  // RMAV_REINMAV only
+    float *pe[3];      // per-env constants (rmav_set_env_param), nullptr = shared
     // scratch for host-pointer calls and layout conversion (grown on demand)
     void *scratch;
     size_t scratch_bytes;
@@ -171,6 +172,7 @@ RolloutArgs base_args(rmav_handle h) {
     a.last_len = h->last_len;
     a.totals = h->totals;
     a.env_time = h->env_time;
+    for (int i = 0; i < 3; ++i) a.pe[i] = h->pe[i];
     a.seed = h->seed;
     a.env_base = h->env_base;
     a.t0 = h->t;
@@ -203,7 +205,7 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
     const ParamsT<double> pc = derive<double>(h->params);
 #define RMAV_CTRL_CASE(KIND)                                                                       \
     hipLaunchKernelGGL((k_control<KIND>), grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,    \
-                       h->n, act_dev, fl, pc)
+                       h->n, act_dev, fl, pc, h->pe[0], h->pe[1], h->pe[2])
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_CTRL_CASE(QUAD2D); break;
     case RMAV_QUAD2D_SL: RMAV_CTRL_CASE(QUAD2D_SL); break;
@@ -249,7 +251,7 @@ template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t cou
 
 void free_all(rmav_handle h) {
     void *ptrs[] = {h->state, h->sbd, h->reset_cnt, h->ep_ret, h->last_ret, h->ep_len, h->last_len,
-                    h->totals, h->env_time, h->scratch};
+                    h->totals, h->env_time, h->pe[0], h->pe[1], h->pe[2], h->scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -484,6 +486,27 @@ int rmav_set_stream(rmav_handle h, void *hip_stream) {
         h->own_stream = true;
     }
     return RMAV_OK;
+}
+
+int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem) {
+    CHECK_HANDLE(h);
+    if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
+    if (which < 0 || which > 2) return fail(RMAV_ERR_INVALID, "unknown env param %d", which);
+    if (h->kind == RMAV_REINMAV) return fail(RMAV_ERR_INVALID, "per-env constants are for the quadrotor kinds");
+    if (!values) {  // back to the shared value
+        if (h->pe[which]) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipFree(h->pe[which]));
+            h->pe[which] = nullptr;
+        }
+        return RMAV_OK;
+    }
+    if (!h->pe[which] && hipMalloc((void **)&h->pe[which], (size_t)h->n * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        h->pe[which] = nullptr;
+        return fail(RMAV_ERR_ALLOC, "device allocation failed");
+    }
+    return copy_in(h, h->pe[which], values, (size_t)h->n, mem);
 }
 
 int64_t rmav_num_envs(rmav_handle h) {

@@ -55,6 +55,7 @@ struct RolloutArgs {
     uint32_t flags;
     float act_lo, act_hi;
     // ACT_POLICY only
+    const float *pe[3];     // optional per-env constants (mass, load mass, tether length), nullptr = shared
     double *env_time;       // REINMAV only: the env's own clock t [N] (fp64: it decides 50 vs 51 sub-steps)
     const float *policy_w;  // packed weights (rmav_policy.hpp layout), device memory
     float *logp_out;        // [n_steps][N]
@@ -94,8 +95,8 @@ __device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t sof
 }
 
 template <int K, int MODE>
-__global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p,
-                                                    const ParamsT<double> pc) {
+__global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
+                                                    const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;  // local env index
     const int64_t n = a.n;
@@ -137,6 +138,20 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         const int32_t sb0 = sb;
         const uint32_t rc0 = rc;
         const uint64_t env_id = a.env_base + (uint64_t)li;
+        // per-env (domain-randomised) constants override the shared kernel arguments for this lane
+        typename Env<K>::P pl = p_shared;
+        ParamsT<double> pcl = pc_shared;
+        if constexpr (K != REINMAV) {
+            if (a.pe[0] || a.pe[1] || a.pe[2]) {
+                const double m = a.pe[0] ? (double)a.pe[0][li] : (double)pc_shared.mass;
+                const double ml = a.pe[1] ? (double)a.pe[1][li] : (double)pc_shared.load_mass;
+                const double L = a.pe[2] ? (double)a.pe[2][li] : (double)pc_shared.L;
+                override_params(pl, m, ml, L);
+                override_params(pcl, m, ml, L);
+            }
+        }
+        const typename Env<K>::P &p = pl;
+        const ParamsT<double> &pc = pcl;
         double tenv = 0.0;
         if constexpr (K == REINMAV) tenv = a.env_time[li];
 
@@ -374,10 +389,15 @@ __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint3
 // control(): state -> action
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_control(const float *state, int64_t n, float *act_out,
-                                                    uint32_t flags, const ParamsT<double> pc) {
+                                                    uint32_t flags, const ParamsT<double> pc_shared,
+                                                    const float *pe_mass, const float *pe_lmass, const float *pe_L) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    ParamsT<double> pc = pc_shared;
+    if (pe_mass || pe_lmass || pe_L)
+        override_params(pc, pe_mass ? (double)pe_mass[i] : pc_shared.mass, pe_lmass ? (double)pe_lmass[i] : pc_shared.load_mass,
+                        pe_L ? (double)pe_L[i] : pc_shared.L);
     float s[NS], act[NA];
 #pragma unroll
     for (int c = 0; c < NS; ++c) s[c] = state[(int64_t)c * n + i];

@@ -66,6 +66,17 @@ template <typename R> struct ParamsT {
     int32_t _pad;
 };
 
+// Re-derive the mass / tether dependent constants for one lane (per-env domain randomisation); same
+// formulas as the host-side derive() in rmav_derive.hpp, evaluated in fp64 and rounded once to R.
+template <typename R> RMAV_HD void override_params(ParamsT<R> &p, double mass, double load_mass, double L) {
+    p.inv_mass = (R)(1.0 / mass);
+    p.mass = (R)mass;
+    p.load_mass = (R)load_mass;
+    p.inv_mtot = (R)(1.0 / (mass + load_mass));
+    p.L = (R)L;
+    p.mL = (R)(mass * L);
+}
+
 // ---- Philox4x32-10 (counter RNG; stream layout documented in include/rmav.h) ----------------------
 RMAV_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                            uint32_t k1, uint32_t (&out)[4]) {

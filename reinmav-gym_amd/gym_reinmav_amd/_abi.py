@@ -17,6 +17,7 @@ KIND_NAMES = {QUAD2D: "quad2d", QUAD2D_SL: "quad2d_sl", QUAD3D: "quad3d", QUAD3D
 KIND_BY_NAME = {v: k for k, v in KIND_NAMES.items()}
 STATE_DIM = {QUAD2D: 5, QUAD2D_SL: 9, QUAD3D: 10, QUAD3D_SL: 16, REINMAV: 13}
 ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4, REINMAV: 4}
+PARAM_MASS, PARAM_LOAD_MASS, PARAM_TETHER_LENGTH = 0, 1, 2
 HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
 ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY = 0, 1, 2, 3
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "rmav_get_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "rmav_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "rmav_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rmav_set_env_param": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int]),
     "rmav_num_envs": (C.c_int64, [C.c_void_p]),
     "rmav_sync": (C.c_int, [C.c_void_p]),
     "rmav_reset": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),

@@ -229,6 +229,16 @@ class BatchedQuadrotor:
         assert rc.shape == (self.num_envs,)
         A.check(self._lib.rmav_set_reset_counts(self._h, self._ptr(rc), A.HOST))
 
+    def set_env_param(self, name: str, values):
+        """Per-env (domain-randomised) constant: name in {'mass', 'load_mass', 'tether_length'}; ``values`` is one
+        float per env (NumPy array or CUDA tensor) or None to return to the shared ``params`` value."""
+        which = {"mass": A.PARAM_MASS, "load_mass": A.PARAM_LOAD_MASS, "tether_length": A.PARAM_TETHER_LENGTH}[name]
+        if values is None:
+            A.check(self._lib.rmav_set_env_param(self._h, which, None, A.HOST))
+            return
+        v, mem = self._in(values, (self.num_envs,))
+        A.check(self._lib.rmav_set_env_param(self._h, which, self._ptr(v), mem))
+
     def get_time(self) -> np.ndarray:
         """'reinmav' envs only: each env's own clock t (float64)."""
         out = np.empty(self.num_envs, dtype=np.float64)

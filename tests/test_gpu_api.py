@@ -214,3 +214,44 @@ def test_multi_shard_all_gather_single_process(G):
     for key in fb:
         assert np.array_equal(np.concatenate([parts[0][key], parts[1][key]]), fb[key])
     full.close()
+
+
+@pytest.mark.parametrize("kind", ["quad3d", "quad3d_sl", "quad2d_sl"])
+def test_per_env_domain_randomised_constants(G, kind):
+    """rmav_set_env_param: per-env mass / load mass / tether length; each env must match the oracle run with
+    that env's own constants (step and controller)."""
+    rng = np.random.RandomState(8)
+    n = 1500
+    s = rng.uniform(-1, 1, (n, NS[kind])).astype(np.float32)
+    a = rng.uniform(-10, 10, (n, NA[kind])).astype(np.float32)
+    mass = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    lmass = rng.uniform(0.05, 0.4, n).astype(np.float32)
+    tether = rng.uniform(0.4, 1.8, n).astype(np.float32)
+    env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
+    env.set_env_param("mass", mass)
+    if kind.endswith("_sl"):
+        env.set_env_param("load_mass", lmass)
+        env.set_env_param("tether_length", tether)
+    env.set_state(s)
+    ctrl = env.control()
+    obs, rew, done = env.step(a)
+    q = O.default_params(kind)
+    for i in range(0, n, 7):
+        q.mass = float(mass[i])
+        if kind.endswith("_sl"):
+            q.load_mass, q.tether_length = float(lmass[i]), float(tether[i])
+        o2, r, d, _ = O.step(kind, s[i].astype(np.float64), a[i].astype(np.float64), params=q)
+        assert scaled_err(obs[i], o2).max() <= TOL
+        if not near_threshold(kind, o2[None])[0]:
+            assert bool(done[i]) == d
+        assert scaled_err(ctrl[i], O.control(kind, s[i].astype(np.float64), params=q)).max() <= CTRL_TOL
+    # back to the shared value
+    env.set_env_param("mass", None)
+    env.set_env_param("load_mass", None)
+    env.set_env_param("tether_length", None)
+    env.set_state(s)
+    env.set_sbd(np.full(n, -1, np.int32))
+    obs, _, _ = env.step(a)
+    o2, _, _, _ = O.batch_step(kind, s.astype(np.float64), a.astype(np.float64))
+    assert scaled_err(obs, o2).max() <= TOL
+    env.close()
