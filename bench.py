@@ -103,6 +103,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    torch.manual_seed(0)  # the step mode's action ring is filled by torch's generator
     kind = args.kind
     n = args.envs_per_gpu
     n_total = n * world
