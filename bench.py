@@ -38,12 +38,28 @@ sys.path.insert(0, os.path.join(ROOT, "reinmav-gym_amd"))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
 
 
-def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: float):
+def _omp_set_threads(k: int):
+    import ctypes
+
+    for name in ("libgomp.so.1", "libomp.so"):
+        try:
+            ctypes.CDLL(name).omp_set_num_threads(int(k))
+            return True
+        except Exception:
+            continue
+    return False
+
+
+def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: float, threads: int = 1):
     """Time the CPU oracle (test infrastructure, used here only as the reported baseline)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
 
     import oracle as O
+
+    O.lib()
+    if not _omp_set_threads(threads):
+        threads = 1
 
     nS = O.STATE_DIM[kind]
     state = np.random.RandomState(0).uniform(-1, 1, (n, nS)).astype(np.float32)
@@ -61,10 +77,11 @@ def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: 
     return {
         "value": done_steps / el,
         "unit": "env-steps/s",
-        "cores": 1,
+        "cores": threads,
         "kind": "port",
-        "sample": f"{kind} C oracle (fp64, scalar, 1 thread), {n} envs x {t} env-steps, random actions + "
-                  f"auto-reset, {el:.1f} s on the GPU box's host CPU ({os.cpu_count()} logical cores present)",
+        "sample": f"{kind} C oracle (fp64, scalar code, {threads} thread{'s' if threads > 1 else ''}), {n} envs x {t} "
+                  f"env-steps, random actions + auto-reset, {el:.1f} s on the GPU box's host CPU "
+                  f"({os.cpu_count()} logical cores present)",
     }
 
 
@@ -246,7 +263,11 @@ def main():
         if secondary:
             line["other_mode"] = secondary
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
+            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            if ncpu > 1:  # same port on every host core the process may use (OpenMP over envs)
+                line["cpu_baseline_all_cores"] = cpu_baseline(kind, n, args.chunk, lo, hi, min(5.0, args.cpu_seconds),
+                                                              threads=ncpu)
         print(json.dumps(line), flush=True)
     env.close()
     if use_dist:

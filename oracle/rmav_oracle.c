@@ -497,6 +497,8 @@ int64_t oracle_rollout_random(int kind, const oracle_params *p, int64_t n, int64
     double acc = 0.0;
     int64_t nd = 0;
     for (int64_t k = 0; k < steps; ++k) {
+        /* envs are independent: with OMP_NUM_THREADS > 1 this is the all-cores CPU baseline */
+#pragma omp parallel for reduction(+ : acc, nd) schedule(static)
         for (int64_t e = 0; e < n; ++e) {
             float af[4];
             double s[16], a[4], o[16], r;

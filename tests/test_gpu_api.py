@@ -255,3 +255,36 @@ def test_per_env_domain_randomised_constants(G, kind):
     o2, _, _, _ = O.batch_step(kind, s.astype(np.float64), a.astype(np.float64))
     assert scaled_err(obs, o2).max() <= TOL
     env.close()
+
+
+def test_rccl_all_gather_single_rank(G, tmp_path):
+    """The per-rollout collective on the real backend: nccl (= RCCL) process group with one rank on the GPU box."""
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    code = f"""
+import os, sys
+sys.path.insert(0, {os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'reinmav-gym_amd')!r})
+import torch, torch.distributed as dist
+import gym_reinmav_amd as g
+from gym_reinmav_amd.distributed import all_gather_episode_stats, all_reduce_totals, make_sharded
+os.environ['MASTER_ADDR']='127.0.0.1'; os.environ['MASTER_PORT']='{port}'
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+env = make_sharded('quad3d', 4099, 0, 1, device=0, seed=1)
+env.rollout(96, mode='random', want=())
+eb = env.episode_buffers(device_out=True)
+r, l = all_gather_episode_stats(eb['last_return'], eb['last_length'], 4099)
+tot = all_reduce_totals(env.episode_totals(), device=torch.device('cuda', 0))
+torch.cuda.synchronize()
+assert torch.equal(r, eb['last_return']) and torch.equal(l, eb['last_length'])
+assert tot == env.episode_totals() and tot['episodes'] > 0
+dist.destroy_process_group()
+print('rccl ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout + r.stderr
