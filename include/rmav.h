@@ -95,8 +95,10 @@ enum rmav_action_mode {
     RMAV_ACT_BUFFER = 0,    /* actions read from a caller buffer */
     RMAV_ACT_RANDOM = 1,    /* uniform in [act_lo, act_hi) from the counter RNG, generated in-kernel */
     RMAV_ACT_CONTROLLER = 2, /* the reference's geometric controller, evaluated in-kernel */
-    RMAV_ACT_POLICY = 3      /* Gaussian MLP policy evaluated in-kernel (rmav_rollout_policy only) */
+    RMAV_ACT_POLICY = 3,     /* Gaussian MLP policy evaluated in-kernel, fp32 (rmav_rollout_policy only) */
+    RMAV_ACT_POLICY_BF16 = 4 /* the same policy on the matrix cores: bf16 operands, fp32 accumulate */
 };
+enum rmav_policy_precision { RMAV_POLICY_FP32 = 0, RMAV_POLICY_BF16_MFMA = 1 };
 
 /* rmav_create flags */
 #define RMAV_F_AUTO_RESET 1u     /* VecEnv semantics: a done env is reset inside step; the returned
@@ -199,11 +201,22 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
  * Per step t: a = mean(obs_t) + exp(logstd) * z_t with z_t standard normal from the counter RNG
  * (stream tag 3, Box-Muller; see csrc/rmav_policy.hpp), logp_out[t] = log N(a; mean, std),
  * value_out[t] = V(obs_t); value_out[n_steps] = V(obs after the last step) for bootstrapping.
- * actions_out [n_steps][nA][N], obs_out [n_steps][nS][N], rew_out / done_out [n_steps][N] may be NULL. */
+ * actions_out [n_steps][nA][N], obs_out [n_steps][nS][N], rew_out / done_out [n_steps][N] may be NULL.
+ * precision = RMAV_POLICY_BF16_MFMA evaluates the same two nets with v_mfma_f32_32x32x16_bf16 (bf16
+ * weights and activations, fp32 accumulation; means / values within ~1e-2 of the fp32 policy).  Its weight
+ * buffer is rmav_policy_weight_count_bf16() floats of pre-arranged MFMA fragments: per net
+ *   A1 [2][64 lanes][8 bf16] | A2 [2][4][64][8] | A3 [4][64][8] | b1 [64] | b2 [64] | b3 [32] (fp32)
+ * then logstd [4]; fragment (.., lane = (m = lane & 31, h = lane >> 5), j) holds
+ *   layer 1: W1p[32 Mt + m][8 h + j]              (W1 zero-padded to 16 inputs)
+ *   layer 2: W2 [32 Mt + m][rowmap(s, h, j)]
+ *   layer 3: W3p[m][rowmap(s, h, j)]               (W3 zero-padded to 32 outputs)
+ *   rowmap(s, h, j) = 32 (s >> 1) + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 (s & 1) + j
+ * (csrc/rmav_policy_mfma.hpp explains why; gym_reinmav_amd.ppo.pack_policy_weights_bf16 builds it). */
 int64_t rmav_policy_weight_count(int kind);
+int64_t rmav_policy_weight_count_bf16(void);
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
-                        float *value_out);
+                        float *value_out, int precision);
 
 /* ---- state access (also the env checkpoint) ------------------------------------------------ */
 int rmav_get_state(rmav_handle h, float *out, int mem, int layout);      /* nS*N floats */

@@ -496,10 +496,11 @@ int64_t oracle_rollout_random(int kind, const oracle_params *p, int64_t n, int64
     int nS = k_state_dim[kind], nA = k_action_dim[kind];
     double acc = 0.0;
     int64_t nd = 0;
-    for (int64_t k = 0; k < steps; ++k) {
-        /* envs are independent: with OMP_NUM_THREADS > 1 this is the all-cores CPU baseline */
+    /* envs are independent, so the env loop is the outer (and, with OMP_NUM_THREADS > 1, the parallel)
+     * one: every env runs its `steps` steps; per-env results do not depend on the thread count */
 #pragma omp parallel for reduction(+ : acc, nd) schedule(static)
-        for (int64_t e = 0; e < n; ++e) {
+    for (int64_t e = 0; e < n; ++e) {
+        for (int64_t k = 0; k < steps; ++k) {
             float af[4];
             double s[16], a[4], o[16], r;
             int d, sb = sbd[e];

@@ -132,7 +132,9 @@ template <int K, int MODE>
 int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    const size_t lds = (MODE == ACT_POLICY) ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL : 0;
+    const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
+                       : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
+                                                   : 0;
     hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
@@ -144,6 +146,7 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     case RMAV_ACT_RANDOM: return launch_rollout_km<K, ACT_RANDOM>(h, a);
     case RMAV_ACT_CONTROLLER: return launch_rollout_km<K, ACT_CONTROLLER>(h, a);
     case RMAV_ACT_POLICY: return launch_rollout_km<K, ACT_POLICY>(h, a);
+    case RMAV_ACT_POLICY_BF16: return launch_rollout_km<K, ACT_POLICY_BF16>(h, a);
     }
     return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
@@ -618,10 +621,14 @@ int64_t rmav_policy_weight_count(int kind) {
     return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
 }
 
+int64_t rmav_policy_weight_count_bf16(void) { return MfmaLayout::TOTAL; }
+
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
-                        float *value_out) {
+                        float *value_out, int precision) {
     CHECK_HANDLE(h);
+    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA)
+        return fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32 or RMAV_POLICY_BF16_MFMA");
     if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (!weights || !logp_out || !value_out)
         return fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
@@ -636,7 +643,7 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
     a.policy_w = weights;
     a.logp_out = logp_out;
     a.val_out = value_out;
-    if (int rc = launch_rollout(h, RMAV_ACT_POLICY, a)) return rc;
+    if (int rc = launch_rollout(h, precision == RMAV_POLICY_FP32 ? RMAV_ACT_POLICY : RMAV_ACT_POLICY_BF16, a)) return rc;
     h->t += (uint64_t)n_steps;
     return RMAV_OK;
 }

@@ -19,10 +19,11 @@
 
 #include "rmav_math.hpp"
 #include "rmav_policy.hpp"
+#include "rmav_policy_mfma.hpp"
 
 namespace rmav {
 
-enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3 };
+enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
 constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
@@ -98,8 +99,13 @@ template <int K, int MODE>
 __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;  // local env index
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
+    // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
+    // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
+    // exactly what that env's lane does; only the episode totals must not count them.
+    const bool valid = gi < (uint64_t)n;
+    const uint32_t li = (MODE == ACT_POLICY_BF16 && !valid) ? (uint32_t)n - 1u : gi;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     float fin_ret = 0.0f;
 
     // ACT_POLICY: stage the policy weights into LDS once per launch (every thread of the block helps)
-    if constexpr (MODE == ACT_POLICY) {
-        constexpr int NW4 = PolicyLayout<NS>::TOTAL / 4;
+    if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
+        constexpr int NW4 = (MODE == ACT_POLICY ? PolicyLayout<NS>::TOTAL : MfmaLayout::TOTAL) / 4;
         const float4 *src = reinterpret_cast<const float4 *>(a.policy_w);
         float4 *dst = reinterpret_cast<float4 *>(lds_w);
         for (int q = threadIdx.x; q < NW4; q += blockDim.x) dst[q] = src[q];
@@ -182,11 +188,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         float *val_out = a.val_out;
         float pol_std[4] = {0.f, 0.f, 0.f, 0.f};
         float pol_logp0 = 0.0f;   // - sum(logstd) - NA/2 * ln(2 pi)
-        if constexpr (MODE == ACT_POLICY) {
+        if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
             float sl = 0.0f;
 #pragma unroll
             for (int c = 0; c < NA; ++c) {
-                const float ls = lds_w[PolicyLayout<NS>::LOGSTD + c];
+                const float ls = lds_w[(MODE == ACT_POLICY ? PolicyLayout<NS>::LOGSTD : MfmaLayout::LOGSTD) + c];
                 pol_std[c] = expf(ls);
                 sl += ls;
             }
@@ -195,7 +201,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
-            if constexpr (MODE == ACT_POLICY) {
+            if constexpr (MODE == ACT_POLICY_BF16) {
+                float x[16], mean[4], val0, z[4];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) x[c] = (c < NS) ? s[c] : 0.0f;
+                policy_forward_mfma(x, mean, val0);
+                gaussian4(a.seed, env_id, a.t0 + (uint64_t)k, z);
+                float q = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) {
+                    act[c] = rfma(pol_std[c], z[c], mean[c]);
+                    q = rfma(z[c], z[c], q);
+                }
+                buf_st(make_rsrc(logp_out), off, 0, rfma(-0.5f, q, pol_logp0));
+                buf_st(make_rsrc(val_out), off, 0, val0);
+                logp_out += n;
+                val_out += n;
+            } else if constexpr (MODE == ACT_POLICY) {
                 using PL = PolicyLayout<NS>;
                 XVec<PL::NSP> x;
 #pragma unroll
@@ -276,9 +298,11 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 if (done) {
                     buf_st(make_rsrc(a.last_ret), off, 0, er);
                     buf_st_i32(make_rsrc(a.last_len), off, 0, el);
-                    fin_n += 1;
-                    fin_len += (unsigned int)el;
-                    fin_ret += er;
+                    if (valid) {
+                        fin_n += 1;
+                        fin_len += (unsigned int)el;
+                        fin_ret += er;
+                    }
                     er = 0.0f;
                     el = 0;
                 }
@@ -315,6 +339,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
             }
         }
 
+        if constexpr (MODE == ACT_POLICY_BF16) {   // bootstrap value of the state the rollout ends in
+            float x[16], mean[4], val0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) x[c] = (c < NS) ? s[c] : 0.0f;
+            policy_forward_mfma(x, mean, val0);
+            buf_st(make_rsrc(val_out), off, 0, val0);
+        }
         if constexpr (MODE == ACT_POLICY) {   // bootstrap value of the state the rollout ends in
             using PL = PolicyLayout<NS>;
             XVec<PL::NSP> x;
@@ -340,14 +371,25 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         // single-step kernel 20 us slower than its memory time).  The adds are result-less atomics:
         // fire-and-forget at the L2, no load -> add -> store round trip at the tail of the kernel.
         // rmav_episode_totals sums the slots.
-        const unsigned int wn = wave_sum(fin_n);
-        const unsigned int wl = wave_sum(fin_len);
-        const float wr = wave_sum(fin_ret);
-        if ((threadIdx.x & 63) == 0 && wn != 0) {
-            Totals *slot = a.totals + (li >> 6);
-            atomicAdd(&slot->episodes, (unsigned long long)wn);
-            atomicAdd(&slot->length_sum, (unsigned long long)wl);
-            atomicAdd(&slot->return_sum, (double)wr);
+        Totals *slot = a.totals + (gi >> 6);
+        if (a.n_steps == 1) {
+            // single-step launches are latency-bound (~4.5 us): three 6-deep shuffle reductions at the tail of
+            // the kernel cost ~0.4 us, while on average fewer than one lane per wavefront finishes an episode
+            // - let those lanes add to the wave's slot themselves.
+            if (fin_n != 0) {
+                atomicAdd(&slot->episodes, (unsigned long long)fin_n);
+                atomicAdd(&slot->length_sum, (unsigned long long)fin_len);
+                atomicAdd(&slot->return_sum, (double)fin_ret);
+            }
+        } else if (__ballot(fin_n != 0) != 0) {
+            const unsigned int wn = wave_sum(fin_n);
+            const unsigned int wl = wave_sum(fin_len);
+            const float wr = wave_sum(fin_ret);
+            if ((threadIdx.x & 63) == 0) {
+                atomicAdd(&slot->episodes, (unsigned long long)wn);
+                atomicAdd(&slot->length_sum, (unsigned long long)wl);
+                atomicAdd(&slot->return_sum, (double)wr);
+            }
         }
     }
 }

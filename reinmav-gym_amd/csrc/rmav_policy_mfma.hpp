@@ -1,0 +1,163 @@
+// rmav_policy_mfma.hpp - bf16-MFMA actor for the fused PPO rollout (RMAV_ACT_POLICY_BF16).
+//
+// The fp32 VALU policy (rmav_policy.hpp) spends ~10 k FMAs per env-step; this is the GEMM-shaped part of
+// the caller loop, so it belongs on the matrix cores.  One wavefront owns 64 envs = two 32-column tiles;
+// every layer is  OUT[64 x 64 envs] = W[64 x K] . IN[K x 64 envs]  done with v_mfma_f32_32x32x16_bf16
+// (bf16 operands, fp32 accumulate), weights as the A operand, activations as the B operand.
+//
+// No activation ever touches LDS or gets transposed between layers:
+//   * C/D layout of the 32x32 MFMA (MI355X guide): lane l = (n = l & 31, h = l >> 5), register r holds
+//     D[row = (r & 3) + 8 (r >> 2) + 4 h][col = n].  So lane (n, h) ends a layer holding, for env column n,
+//     the 16 rows {(r&3) + 8(r>>2) + 4h} of each 32-row tile.
+//   * A B operand is 8 bf16 per lane: slot (h, j), j = 0..7, of K-slice s.  The hardware pairs A-slot (h, j)
+//     with B-slot (h, j), whatever it calls that k.  We therefore feed K-slice s of the NEXT layer straight
+//     from accumulator registers r = 8 (s & 1) + j of row tile T = s >> 1 (after tanh and bf16 rounding), and
+//     the host packs W's columns in the matching order:  A-slot (h, j) of slice s, lane (m, h)  =
+//     W[m][32 T + (r & 3) + 8 (r >> 2) + 4 h].   (rowmap() below; pack_policy_weights_bf16 in ppo.py.)
+//   * Only the network input and output cross lanes: env e lives in lane e, but column tile Nt needs env
+//     32 Nt + n in both half-waves, so the state is exchanged once between lanes l and l ^ 32 (8 shuffles),
+//     and the action mean / value come back the same way (5 shuffles).
+//
+// LDS holds the pre-arranged bf16 weight fragments (one ds_read_b128 per lane per fragment, conflict-free:
+// consecutive lanes read consecutive 16-byte slots) and the fp32 biases (read as the C operand's initial
+// value, 4 consecutive rows per ds_read_b128).  ~30 KB per policy.
+//
+// Precision: bf16 operands (8 mantissa bits) with fp32 accumulation: means / values agree with the fp32
+// policy to ~1e-2 (tested at 3e-2 * max(1, |y|)); log-probabilities are exact for the action actually taken
+// under the bf16 mean.  That is an actor/learner precision split, so it is opt-in (the default ACT_POLICY
+// mode is fp32 and agrees with torch to 2e-5).
+#pragma once
+
+#include "rmav_policy.hpp"
+
+namespace rmav {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// float offsets inside the LDS buffer (one float = 4 bytes; a fragment = 64 lanes x 16 B = 256 floats)
+struct MfmaLayout {
+    static constexpr int FRAG = 256;
+    static constexpr int A1 = 0;                    // [Mt=2]            layer 1 (K = 16: the padded state)
+    static constexpr int A2 = A1 + 2 * FRAG;        // [Mt=2][s=4]       layer 2
+    static constexpr int A3 = A2 + 8 * FRAG;        // [s=4]             layer 3 (output rows padded to 32)
+    static constexpr int B1 = A3 + 4 * FRAG;        // fp32 bias tables: 64, 64, 32 rows
+    static constexpr int B2 = B1 + 64;
+    static constexpr int B3 = B2 + 64;
+    static constexpr int NET = B3 + 32;             // floats per net
+    static constexpr int LOGSTD = 2 * NET;
+    static constexpr int TOTAL = 2 * NET + 4;
+};
+
+// C operand initialised with the bias of the rows this lane holds: rows 32 T + 8 q + 4 h + {0..3} for q = 0..3
+__device__ __forceinline__ f32x16_t bias_frag(const float *tab, uint32_t h) {
+    f32x16_t c;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(tab + 8 * q + 4 * h);
+        c[4 * q + 0] = b.x; c[4 * q + 1] = b.y; c[4 * q + 2] = b.z; c[4 * q + 3] = b.w;
+    }
+    return c;
+}
+
+__device__ __forceinline__ bf16x8_t ld_frag(const float *base, uint32_t lane) {
+    return *reinterpret_cast<const bf16x8_t *>(base + lane * 4u);   // 16 bytes per lane
+}
+
+// registers [8 half .. 8 half + 8) of an accumulator -> tanh -> bf16 B fragment
+__device__ __forceinline__ bf16x8_t act_frag(const f32x16_t &acc, int half) {
+    bf16x8_t b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)tanh_fast(acc[8 * half + j]);
+    return b;
+}
+
+// One net (weights at float offset `net` of lds_w) for the two column tiles of this wavefront.
+// b_in0 / b_in1: layer-1 B fragments of the two column tiles.  Returns the first 4 output rows of each
+// column tile (valid in lanes with h == 0).
+struct MlpOut { float t0[4], t1[4]; };   // first 4 output rows of column tile 0 / 1 (returned in VGPRs)
+
+__device__ __noinline__ MlpOut mlp_mfma(bf16x8_t b_in0, bf16x8_t b_in1, uint32_t net) {
+    using L = MfmaLayout;
+    asm volatile("" : "+v"(net));   // keep LLVM from hoisting the weight reads out of the env-step loop
+    const float *w = lds_w + net;
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    // ---- layer 1: [64 x 16] . [16 x 32] per column tile -------------------------------------------------
+    f32x16_t acc[2][2];   // [row tile T][column tile Nt]
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const bf16x8_t a = ld_frag(w + L::A1 + T * L::FRAG, lane);
+        const f32x16_t c = bias_frag(w + L::B1 + 32 * T, h);
+        acc[T][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_in0, c, 0, 0, 0);
+        acc[T][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b_in1, c, 0, 0, 0);
+    }
+    // ---- layer 2: K = 64 hidden units = 4 slices fed straight from the accumulators -----------------------
+    bf16x8_t hb[2][4];    // [Nt][s]
+#pragma unroll
+    for (int Nt = 0; Nt < 2; ++Nt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag(acc[s >> 1][Nt], s & 1);
+    f32x16_t acc2[2][2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        const f32x16_t c = bias_frag(w + L::B2 + 32 * T, h);
+        acc2[T][0] = c;
+        acc2[T][1] = c;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8_t a = ld_frag(w + L::A2 + (T * 4 + s) * L::FRAG, lane);
+            acc2[T][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][s], acc2[T][0], 0, 0, 0);
+            acc2[T][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][s], acc2[T][1], 0, 0, 0);
+        }
+    }
+    // ---- layer 3: output rows padded to one 32-row tile ---------------------------------------------------
+#pragma unroll
+    for (int Nt = 0; Nt < 2; ++Nt)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag(acc2[s >> 1][Nt], s & 1);
+    f32x16_t o0 = bias_frag(w + L::B3, h), o1 = o0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8_t a = ld_frag(w + L::A3 + s * L::FRAG, lane);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[0][s], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, hb[1][s], o1, 0, 0, 0);
+    }
+    MlpOut out;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // rows 0..3 = registers 0..3 of the lanes with h == 0
+        out.t0[r] = o0[r];
+        out.t1[r] = o1[r];
+    }
+    return out;
+}
+
+// Policy mean (4 padded outputs) and value for the env owned by this lane.  x: the env's state padded to 16.
+__device__ __forceinline__ void policy_forward_mfma(const float (&x)[16], float (&mean)[4], float &value) {
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    // B fragment of column tile Nt, lane (n, h): components [8h, 8h+8) of env 32 Nt + n.
+    // Own tile (Nt == h): own components.  Other tile: the partner lane l ^ 32 owns that env; it needs my
+    // components [8 (1-h), ...) for its own fragment, I need its components [8h, ...).
+    bf16x8_t own, other;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float mine = h ? x[8 + j] : x[j];        // x[8h + j]
+        const float send = h ? x[j] : x[8 + j];        // x[8(1-h) + j]: what the partner's fragment needs
+        const float recv = __shfl_xor(send, 32, 64);
+        own[j] = (__bf16)mine;
+        other[j] = (__bf16)recv;
+    }
+    const bf16x8_t b0 = h ? other : own;   // column tile 0 = envs of lanes 0..31
+    const bf16x8_t b1 = h ? own : other;   // column tile 1 = envs of lanes 32..63
+    const MlpOut m = mlp_mfma(b0, b1, 0u);
+    const MlpOut v = mlp_mfma(b0, b1, (uint32_t)MfmaLayout::NET);
+    // results sit in the h == 0 lanes: tile 0 is already home, tile 1 goes to the partner lane
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float from_partner = __shfl_xor(m.t1[r], 32, 64);
+        mean[r] = h ? from_partner : m.t0[r];
+    }
+    const float vp = __shfl_xor(v.t1[0], 32, 64);
+    value = h ? vp : v.t0[0];
+}
+
+}  // namespace rmav

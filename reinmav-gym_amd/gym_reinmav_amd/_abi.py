@@ -20,7 +20,8 @@ ACTION_DIM = {QUAD2D: 2, QUAD2D_SL: 2, QUAD3D: 4, QUAD3D_SL: 4, REINMAV: 4}
 PARAM_MASS, PARAM_LOAD_MASS, PARAM_TETHER_LENGTH = 0, 1, 2
 HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
-ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY = 0, 1, 2, 3
+ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY, ACT_POLICY_BF16 = 0, 1, 2, 3, 4
+POLICY_FP32, POLICY_BF16_MFMA = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
 
@@ -85,7 +86,8 @@ PROTOTYPES = {
     "rmav_rollout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int, C.c_int,
                                C.c_int]),
     "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
-    "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp]),
+    "rmav_policy_weight_count_bf16": (C.c_int64, []),
+    "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp, C.c_int]),
     "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_set_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_get_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),

@@ -134,31 +134,102 @@ class RolloutCollector:
         self.obs[0].copy_(self.obs[self.T])
 
 
+def _rowmap(s: int, h: int, j: int) -> int:
+    """Row of the previous layer's output that MFMA B-slot (h, j) of K-slice s carries (csrc/rmav_policy_mfma.hpp)."""
+    r = 8 * (s & 1) + j
+    return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h
+
+
+class _PolicyPacker:
+    """Packs an ``MlpPolicy`` into the weight buffer ``rmav_rollout_policy`` reads (layouts in include/rmav.h).
+
+    The layouts are fixed permutations (+ zero padding) of the flattened parameters, so the index map is
+    built once (NumPy, host) and every repack is: one ``cat`` of the parameters, one gather, and for the
+    bf16 fragments one dtype conversion - a handful of launches, cheap enough to run before every rollout."""
+
+    def __init__(self, policy: MlpPolicy, n_obs: int, bf16_mfma: bool):
+        import numpy as np
+
+        H = policy.pi[0].out_features
+        assert H == 64 and policy.pi[1].in_features == 64, "the in-kernel policy is the 2 x 64 baselines mlp"
+        assert n_obs <= 16
+        self.policy, self.bf16 = policy, bool(bf16_mfma)
+        self.params = [policy.pi[0].weight, policy.pi[0].bias, policy.pi[1].weight, policy.pi[1].bias,
+                       policy.pi[2].weight, policy.pi[2].bias, policy.vf[0].weight, policy.vf[0].bias,
+                       policy.vf[1].weight, policy.vf[1].bias, policy.vf[2].weight, policy.vf[2].bias, policy.logstd]
+        offs = np.cumsum([0] + [p.numel() for p in self.params])
+        ZERO = int(offs[-1])                       # index of the appended 0.0
+        n_act = policy.logstd.numel()
+
+        def W(net, layer, r, c):                   # flat index of weight[r][c] (or ZERO when outside the matrix)
+            p = self.params[6 * net + 2 * layer]
+            rows, cols = p.shape
+            return int(offs[6 * net + 2 * layer]) + r * cols + c if (r < rows and c < cols) else ZERO
+
+        def Bv(net, layer, r):
+            p = self.params[6 * net + 2 * layer + 1]
+            return int(offs[6 * net + 2 * layer + 1]) + r if r < p.numel() else ZERO
+
+        logstd = [int(offs[12]) + c if c < n_act else ZERO for c in range(4)]
+        if not self.bf16:
+            nsp = (n_obs + 3) // 4 * 4
+            idx = []
+            for net in range(2):
+                idx += [W(net, 0, jj, i) for jj in range(H) for i in range(nsp)]          # W1 [H][NSP]
+                idx += [Bv(net, 0, jj) for jj in range(H)]
+                idx += [W(net, 1, jj, i) for i in range(H) for jj in range(H)]            # W2T[i][j] = W2[j][i]
+                idx += [Bv(net, 1, jj) for jj in range(H)]
+                idx += [W(net, 2, k, jj) for jj in range(H) for k in range(4)]            # W3T[j][k] = W3[k][j]
+                idx += [Bv(net, 2, k) for k in range(4)]
+            idx += logstd
+            self.idx_f32 = torch.tensor(idx, dtype=torch.int64, device=policy.logstd.device)
+            self.n_out = len(idx)
+        else:
+            frag, f32 = [], []                     # per net: bf16 fragment indices, fp32 (bias) indices
+            for net in range(2):
+                fr = []
+                for Mt in range(2):                # A1[Mt][lane][j] = W1p[32 Mt + m][8 h + j]
+                    fr += [W(net, 0, 32 * Mt + (l & 31), 8 * (l >> 5) + jj) for l in range(64) for jj in range(8)]
+                for Mt in range(2):                # A2[Mt][s][lane][j] = W2[32 Mt + m][rowmap(s, h, j)]
+                    for s_ in range(4):
+                        fr += [W(net, 1, 32 * Mt + (l & 31), _rowmap(s_, l >> 5, jj)) for l in range(64) for jj in range(8)]
+                for s_ in range(4):                # A3[s][lane][j] = W3p[m][rowmap(s, h, j)]
+                    fr += [W(net, 2, l & 31, _rowmap(s_, l >> 5, jj)) for l in range(64) for jj in range(8)]
+                frag.append(fr)
+                f32.append([Bv(net, 0, r) for r in range(64)] + [Bv(net, 1, r) for r in range(64)] +
+                           [Bv(net, 2, r) for r in range(32)])
+            dev = policy.logstd.device
+            self.idx_frag = torch.tensor(frag[0] + frag[1], dtype=torch.int64, device=dev)
+            self.idx_bias = torch.tensor(f32[0] + f32[1] + logstd, dtype=torch.int64, device=dev)
+            self.n_frag = len(frag[0]) // 2        # floats per net of fragments (2 bf16 per float)
+            self.n_bias = len(f32[0])
+            self.n_out = 2 * (self.n_frag + self.n_bias) + 4
+
+    def pack(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in self.params] + [torch.zeros(1, device=self.params[0].device)])
+            if not self.bf16:
+                res = flat[self.idx_f32]
+            else:
+                fr = flat[self.idx_frag].to(torch.bfloat16).view(torch.int16).view(torch.float32)   # [2 * n_frag]
+                bi = flat[self.idx_bias]
+                res = torch.cat([fr[:self.n_frag], bi[:self.n_bias], fr[self.n_frag:], bi[self.n_bias:2 * self.n_bias],
+                                 bi[2 * self.n_bias:]])
+            if out is not None:
+                out.copy_(res)
+                return out
+            return res.contiguous()
+
+
 def pack_policy_weights(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Flatten an ``MlpPolicy`` into the buffer layout ``rmav_rollout_policy`` reads (include/rmav.h):
-    per net  W1 [64][NSP] | b1 | W2^T [64][64] | b2 | W3^T [64][4] | b3 [4],  then logstd [4]."""
-    H = policy.pi[0].out_features
-    assert H == 64 and policy.pi[1].in_features == 64, "the in-kernel policy is the 2 x 64 baselines mlp"
-    nsp = (n_obs + 3) // 4 * 4
-    dev = policy.logstd.device
-    parts = []
-    for net in (policy.pi, policy.vf):
-        w1 = torch.zeros((H, nsp), device=dev)
-        w1[:, :n_obs] = net[0].weight.detach()
-        w3t = torch.zeros((H, 4), device=dev)
-        w3t[:, :net[2].out_features] = net[2].weight.detach().t()
-        b3 = torch.zeros(4, device=dev)
-        b3[:net[2].out_features] = net[2].bias.detach()
-        parts += [w1.reshape(-1), net[0].bias.detach(), net[1].weight.detach().t().contiguous().reshape(-1),
-                  net[1].bias.detach(), w3t.reshape(-1), b3]
-    ls = torch.zeros(4, device=dev)
-    ls[:policy.logstd.numel()] = policy.logstd.detach()
-    parts.append(ls)
-    flat = torch.cat([p.float() for p in parts])
-    if out is not None:
-        out.copy_(flat)
-        return out
-    return flat.contiguous()
+    """fp32 layout: per net  W1 [64][NSP] | b1 | W2^T [64][64] | b2 | W3^T [64][4] | b3 [4],  then logstd [4]."""
+    return _PolicyPacker(policy, n_obs, False).pack(out)
+
+
+def pack_policy_weights_bf16(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 MFMA fragments: per net A1 [2][64][8] | A2 [2][4][64][8] | A3 [4][64][8] (bf16) | b1 [64] | b2 [64] |
+    b3 [32] (fp32), then logstd [4]."""
+    return _PolicyPacker(policy, n_obs, True).pack(out)
 
 
 class FusedPolicyCollector:
@@ -166,13 +237,14 @@ class FusedPolicyCollector:
     (2 x 64 tanh MLP + value net, weights staged in LDS) is evaluated inside the rollout kernel by the lane
     that owns the env (``rmav_rollout_policy``), so nothing but the trajectory touches HBM."""
 
-    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int):
+    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, bf16_mfma: bool = False):
         import ctypes as C
 
         from . import _abi as A
 
         assert env.auto_reset, "rollouts need VecEnv semantics (auto-reset)"
         self.env, self.policy, self.T = env, policy, int(nsteps)
+        self.bf16_mfma = bool(bf16_mfma)
         self._C, self._A = C, A
         dev = torch.device("cuda", env.device)
         N, nS, nA, T = env.num_envs, env.nS, env.nA, self.T
@@ -183,18 +255,20 @@ class FusedPolicyCollector:
         self.val = torch.empty((T + 1, N), **f32)
         self.rew = torch.empty((T, N), **f32)
         self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
-        n_w = A.lib().rmav_policy_weight_count(env.kind)
+        n_w = A.lib().rmav_policy_weight_count_bf16() if self.bf16_mfma else A.lib().rmav_policy_weight_count(env.kind)
         self.weights = torch.empty(n_w, **f32)
         assert self.weights.data_ptr() % 16 == 0
+        self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma)
+        assert self._packer.n_out == n_w, (self._packer.n_out, n_w)
         self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
 
     def collect(self):
         C, A = self._C, self._A
-        w = pack_policy_weights(self.policy, self.env.nS, out=self.weights)
-        assert w.numel() == self.weights.numel()
+        self._packer.pack(out=self.weights)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         A.check(A.lib().rmav_rollout_policy(self.env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]),
-                                            p(self.rew), p(self.done), p(self.logp), p(self.val)))
+                                            p(self.rew), p(self.done), p(self.logp), p(self.val),
+                                            A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32))
         return self
 
     def roll_over(self):

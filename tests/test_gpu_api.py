@@ -1,5 +1,6 @@
 """The drop-in boundary on the GPU: gym.Env-shaped single envs, the VecEnv contract, error behaviour."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest

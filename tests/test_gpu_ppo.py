@@ -162,3 +162,50 @@ def test_fused_policy_learner_loop(G):
     assert hist[-1]["explained_variance"] > max(0.02, hist[0]["explained_variance"])
     assert all(h["ratio_max"] < 5.0 for h in hist)   # rollout logp (kernel) and learner logp (torch) agree
     env.close()
+
+
+@pytest.mark.parametrize("kind,n", [("quad3d", 512), ("quad3d_sl", 300), ("quad2d", 131), ("reinmav", 64)])
+def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n):
+    """RMAV_POLICY_BF16_MFMA: the same two nets on the matrix cores (bf16 operands, fp32 accumulate).  Means and
+    values must agree with the fp32 torch policy to bf16 accuracy for EVERY env of full, partial and
+    single wavefronts (the inter-lane exchange and the fragment packing are what this checks); the env side
+    and the noise spec are the same code as the fp32 mode."""
+    import torch
+    from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
+
+    torch.manual_seed(5)
+    T, seed = 6, 33
+    env = G.BatchedQuadrotor(kind, n, seed=seed)
+    if kind == "reinmav":   # spread the envs out (they all start from the same init state)
+        s0 = env.get_state() + np.random.RandomState(0).normal(scale=0.1, size=(n, 13)).astype(np.float32)
+        env.set_state(s0)
+    pol = MlpPolicy(env.nS, env.nA, init_logstd=-1.0).cuda()
+    with torch.no_grad():
+        for net in (pol.pi, pol.vf):
+            net[2].weight.mul_(20.0 if net is pol.pi else 1.0)
+            for lin in net:
+                lin.bias.uniform_(-0.3, 0.3)
+        pol.logstd.copy_(torch.linspace(-1.2, -0.4, env.nA))
+    ro = FusedPolicyCollector(env, pol, T, bf16_mfma=True)
+    t0 = env.step_count
+    ro.collect()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        obs = ro.obs[:T].permute(1, 0, 2).reshape(env.nS, -1)
+        mean, val = pol(obs)
+        mean, val = mean.reshape(env.nA, T, n), val.reshape(T, n)
+        v_last = pol(ro.obs[T])[1]
+        std = torch.exp(pol.logstd)[:, None, None]
+    scale_m = max(1.0, float(mean.abs().max()))
+    scale_v = max(1.0, float(val.abs().max()))
+    assert (ro.val[:T] - val).abs().max() < 3e-2 * scale_v
+    assert (ro.val[T] - v_last).abs().max() < 3e-2 * scale_v
+    # implied noise must match the Philox/Box-Muller spec up to the bf16 error of the mean
+    z = ((ro.act.permute(1, 0, 2) - mean) / std).cpu().numpy()
+    for t in (0, T - 1):
+        zp = _predicted_noise(seed, np.arange(n), t0 + t)[:, :env.nA]
+        assert np.abs(z[:, t, :].T - zp).max() < 3e-2 * scale_m / float(std.min())
+    logp_ref = -0.5 * torch.from_numpy(_predicted_noise(seed, np.arange(n), t0)[:, :env.nA] ** 2).sum(1) \
+        - float(pol.logstd.sum()) - 0.5 * env.nA * np.log(2 * np.pi)
+    assert (ro.logp[0].cpu() - logp_ref).abs().max() < 1e-3
+    env.close()
