@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--chunk", type=int, default=32, help="env-steps per launch in rollout mode")
+    ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other mode's short measurement")
     args = ap.parse_args()
@@ -140,16 +141,17 @@ def main():
         def make_runner(mode, chunk):
             """Returns (run(k): enqueue k launches, env-steps per env per launch)."""
             if mode == "rollout":
+                shp = (lambda d: (chunk, d, n)) if args.layout == "soa" else (lambda d: (chunk, n, d))
                 bufs = {
-                    "actions": torch.empty((chunk, nA, n), dtype=torch.float32, device=dev),
-                    "obs": torch.empty((chunk, nS, n), dtype=torch.float32, device=dev),
+                    "actions": torch.empty(shp(nA), dtype=torch.float32, device=dev),
+                    "obs": torch.empty(shp(nS), dtype=torch.float32, device=dev),
                     "rew": torch.empty((chunk, n), dtype=torch.float32, device=dev),
                     "done": torch.empty((chunk, n), dtype=torch.uint8, device=dev),
                 }
 
                 def run(k):
                     for _ in range(k):
-                        env.rollout(chunk, mode="random", layout="soa", fused=True,
+                        env.rollout(chunk, mode="random", layout=args.layout, fused=True,
                                     want=("actions", "obs", "rew", "done"), device_out=True, out=bufs)
                 return run, chunk
             # step mode: one launch per env-step; the launch loop runs inside librmav (rmav_rollout with
