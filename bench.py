@@ -267,9 +267,16 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            if ncpu > 1:  # same port on every host core the process may use (OpenMP over envs)
-                line["cpu_baseline_all_cores"] = cpu_baseline(kind, n, args.chunk, lo, hi, min(5.0, args.cpu_seconds),
-                                                              threads=ncpu)
+            if ncpu > 1:
+                # the same port with OpenMP over envs.  Containers often expose more logical CPUs than their
+                # quota lets them use, so a few thread counts are tried briefly and the best one is reported
+                # (cores = the threads actually used for that number).
+                best = None
+                for k in sorted({c for c in (4, 16, 64, ncpu) if c <= ncpu}):
+                    r = cpu_baseline(kind, n, args.chunk, lo, hi, min(1.5, args.cpu_seconds), threads=k)
+                    if best is None or r["value"] > best["value"]:
+                        best = r
+                line["cpu_baseline_multithread"] = best
         print(json.dumps(line), flush=True)
     env.close()
     if use_dist:
