@@ -98,6 +98,7 @@ enum rmav_action_mode {
     RMAV_ACT_POLICY = 3,     /* Gaussian MLP policy evaluated in-kernel, fp32 (rmav_rollout_policy only) */
     RMAV_ACT_POLICY_BF16 = 4 /* the same policy on the matrix cores: bf16 operands, fp32 accumulate */
 };
+enum rmav_integrator { RMAV_INT_EULER = 0, RMAV_INT_RK4 = 1 };
 enum rmav_policy_precision { RMAV_POLICY_FP32 = 0, RMAV_POLICY_BF16_MFMA = 1 };
 
 /* rmav_create flags */
@@ -117,7 +118,9 @@ typedef struct rmav_params {
     double vel_limit;     /* ... or |vel| > vel_limit */
     double thrust_scale;  /* quadrotor2d.py:75 (10 for quad2d, 1 otherwise) */
     int32_t clamp_thrust; /* quadrotor2d.py:76-77 (1 for quad2d) */
-    int32_t _pad;
+    int32_t integrator;   /* RMAV_REINMAV only: RMAV_INT_EULER (0, the reference: reinmav_env.py:90-98) or
+                             RMAV_INT_RK4 (1: classical Runge-Kutta over the same sub-step grid, command held over
+                             each sub-step; an option the reference does not have) */
     double ref_pos[3];    /* controller set-point  quadrotor3d.py:51 */
     double ref_vel[3];    /* quadrotor3d.py:52 */
     double kp, kv, tau;   /* controller gains  quadrotor3d.py:143-145, quadrotor2d.py:116-118 */

@@ -219,27 +219,30 @@ def reinmav_params() -> ReinmavParams:
     return p
 
 
-def reinmav_step(s, t: float, action=None, params: ReinmavParams | None = None):
-    """One env, one step (50/51 Euler sub-steps).  Returns (s_next f64[13], t_next, reward, done, n_substeps)."""
+def reinmav_step(s, t: float, action=None, params: ReinmavParams | None = None, rk4: bool = False):
+    """One env, one step (50/51 Euler sub-steps; rk4=True: RK4 sub-steps, not in the reference).
+    Returns (s_next f64[13], t_next, reward, done, n_substeps)."""
     L = lib()
     L.oracle_reinmav_step.restype = C.c_int
+    L.oracle_reinmav_step_rk4.restype = C.c_int
     p = params or reinmav_params()
     s = np.array(s, dtype=np.float64, copy=True)
     tt = C.c_double(float(t))
     r, d = C.c_double(), C.c_int()
     a = None if action is None else np.ascontiguousarray(action, dtype=np.float64)
-    n = L.oracle_reinmav_step(C.byref(p), _dptr(s), C.byref(tt), None if a is None else _dptr(a), C.byref(r), C.byref(d))
+    fn = L.oracle_reinmav_step_rk4 if rk4 else L.oracle_reinmav_step
+    n = fn(C.byref(p), _dptr(s), C.byref(tt), None if a is None else _dptr(a), C.byref(r), C.byref(d))
     return s, tt.value, r.value, bool(d.value), n
 
 
-def reinmav_batch_step(S, T, actions=None, params: ReinmavParams | None = None):
+def reinmav_batch_step(S, T, actions=None, params: ReinmavParams | None = None, rk4: bool = False):
     """S [n,13], T [n] -> (S_next [n,13], T_next [n], n_substeps [n])."""
     p = params or reinmav_params()
     S = np.array(S, dtype=np.float64, copy=True)
     T = np.array(T, dtype=np.float64, copy=True)
     ns = np.zeros(len(S), np.int32)
     for i in range(len(S)):
-        S[i], T[i], _, _, ns[i] = reinmav_step(S[i], T[i], None if actions is None else actions[i], p)
+        S[i], T[i], _, _, ns[i] = reinmav_step(S[i], T[i], None if actions is None else actions[i], p, rk4=rk4)
     return S, T, ns
 
 

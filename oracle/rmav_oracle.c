@@ -687,3 +687,29 @@ int oracle_reinmav_step(const oracle_reinmav_params *p, double s[13], double *t,
     *t = *t + p->dt;        /* :119 */
     return n;
 }
+
+int oracle_reinmav_step_rk4(const oracle_reinmav_params *p, double s[13], double *t, const double *action,
+                            double *reward, int *done) {
+    const double start = *t, stop = *t + p->dt, ds = p->ds;
+    int n = (int)ceil((stop - start) / ds);
+    if (n < 0) n = 0;
+    const double delta = (start + ds) - start;
+    for (int i = 0; i < n; ++i) {
+        double ti = (i == 0) ? start : ((i == 1) ? start + ds : start + i * delta);
+        double fm[4], k1[13], k2[13], k3[13], k4[13], y[13];
+        if (action) memcpy(fm, action, sizeof(fm));
+        else oracle_reinmav_controller(p, s, ti, fm);
+        oracle_reinmav_derivative(p, s, fm, k1);
+        for (int k = 0; k < 13; ++k) y[k] = s[k] + 0.5 * ds * k1[k];
+        oracle_reinmav_derivative(p, y, fm, k2);
+        for (int k = 0; k < 13; ++k) y[k] = s[k] + 0.5 * ds * k2[k];
+        oracle_reinmav_derivative(p, y, fm, k3);
+        for (int k = 0; k < 13; ++k) y[k] = s[k] + ds * k3[k];
+        oracle_reinmav_derivative(p, y, fm, k4);
+        for (int k = 0; k < 13; ++k) s[k] = s[k] + ds / 6.0 * (k1[k] + 2.0 * k2[k] + 2.0 * k3[k] + k4[k]);
+    }
+    *reward = 100.0 - 10.0;
+    *done = 1;
+    *t = *t + p->dt;
+    return n;
+}

@@ -111,6 +111,10 @@ void oracle_reinmav_derivative(const oracle_reinmav_params *p, const double s[13
  * done is always 1.  Returns the number of sub-steps taken. */
 int oracle_reinmav_step(const oracle_reinmav_params *p, double s[13], double *t, const double *action,
                         double *reward, int *done);
+/* Same with classical RK4 sub-steps (command held over each sub-step) - NOT in the reference; it checks the
+ * product's optional RMAV_INT_RK4 integrator. */
+int oracle_reinmav_step_rk4(const oracle_reinmav_params *p, double s[13], double *t, const double *action,
+                            double *reward, int *done);
 
 #ifdef __cplusplus
 }

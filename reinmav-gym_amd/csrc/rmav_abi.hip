@@ -93,6 +93,8 @@ struct DeviceGuard {
     if (!guard_.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", h->device)
 
 int check_params(const rmav_params &q) {
+    if (q.integrator != RMAV_INT_EULER && q.integrator != RMAV_INT_RK4)
+        return fail(RMAV_ERR_INVALID, "rmav_params.integrator must be RMAV_INT_EULER or RMAV_INT_RK4");
     if (!(q.mass > 0) || !(q.dt > 0) || !(q.tau != 0) || !(q.mass + q.load_mass > 0))
         return fail(RMAV_ERR_INVALID, "rmav_params: mass, dt must be > 0 and tau != 0");
     return RMAV_OK;

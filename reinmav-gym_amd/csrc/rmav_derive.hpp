@@ -68,6 +68,7 @@ inline ReinmavP derive_reinmav(const rmav_params &q) {
     memcpy(p.kd, kd, sizeof(kd));
     memcpy(p.kp_rot, kpr, sizeof(kpr));
     memcpy(p.kd_rot, kdr, sizeof(kdr));
+    p.rk4 = (q.integrator == RMAV_INT_RK4) ? 1 : 0;
     return p;
 }
 

@@ -455,6 +455,8 @@ struct ReinmavP {
     double inertia[3][3], inv_inertia[3][3];
     double dt, ds, t_max;
     double kp[3], kd[3], kp_rot[3], kd_rot[3];
+    int32_t rk4;   // 0: explicit Euler sub-steps (the reference), 1: RK4 sub-steps
+    int32_t _pad;
 };
 
 RMAV_HD void reinmav_quat2mat(const double (&q)[4], double (&m)[3][3]) {   // quat2mat :267-290
@@ -505,8 +507,8 @@ RMAV_HD void reinmav_controller(const ReinmavP &p, const double (&s)[13], double
     fm[3] = p.kp_rot[2] * (psi_des - psi) + p.kd_rot[2] * (dpsi_des - s[12]);
 }
 
-// quad_eq_of_motion2 (:203-264): one explicit Euler sub-step  s <- s + ds * f(s, F, M)
-RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&fm)[4]) {
+// quad_eq_of_motion2 (:203-264): sdot = f(s, F, M)
+RMAV_HD void reinmav_derivative(const ReinmavP &p, const double (&s)[13], const double (&fm)[4], double (&sd)[13]) {
     const double L = p.arm_length, k = 0.5 / L;
     double T[4] = {0.25 * fm[0] - k * fm[2], 0.25 * fm[0] + k * fm[1], 0.25 * fm[0] + k * fm[2], 0.25 * fm[0] - k * fm[1]};
 #pragma unroll
@@ -534,16 +536,38 @@ RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&
     rhs[0] = mom[0] - (w[1] * Iw[2] - w[2] * Iw[1]);
     rhs[1] = mom[1] - (w[2] * Iw[0] - w[0] * Iw[2]);
     rhs[2] = mom[2] - (w[0] * Iw[1] - w[1] * Iw[0]);
-    const double ds = p.ds;
-    const double v0 = s[3], v1 = s[4], v2 = s[5];
-    s[0] = rfma(ds, v0, s[0]); s[1] = rfma(ds, v1, s[1]); s[2] = rfma(ds, v2, s[2]);
+    sd[0] = s[3]; sd[1] = s[4]; sd[2] = s[5];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) s[3 + i] = rfma(ds, acc[i], s[3 + i]);
+    for (int i = 0; i < 3; ++i) sd[3 + i] = acc[i];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s[6 + i] = rfma(ds, qd[i], s[6 + i]);
+    for (int i = 0; i < 4; ++i) sd[6 + i] = qd[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-        s[10 + i] = rfma(ds, p.inv_inertia[i][0] * rhs[0] + p.inv_inertia[i][1] * rhs[1] + p.inv_inertia[i][2] * rhs[2], s[10 + i]);
+        sd[10 + i] = p.inv_inertia[i][0] * rhs[0] + p.inv_inertia[i][1] * rhs[1] + p.inv_inertia[i][2] * rhs[2];
+}
+
+// one sub-step of length ds with the command held:  explicit Euler (the reference, :98) or classical RK4
+RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&fm)[4]) {
+    const double ds = p.ds;
+    double k1[13];
+    reinmav_derivative(p, s, fm, k1);
+    if (!p.rk4) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s[i] = rfma(ds, k1[i], s[i]);
+        return;
+    }
+    double k2[13], k3[13], k4[13], y[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y[i] = rfma(0.5 * ds, k1[i], s[i]);
+    reinmav_derivative(p, y, fm, k2);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y[i] = rfma(0.5 * ds, k2[i], s[i]);
+    reinmav_derivative(p, y, fm, k3);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) y[i] = rfma(ds, k3[i], s[i]);
+    reinmav_derivative(p, y, fm, k4);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) s[i] = rfma(ds / 6.0, (k1[i] + 2.0 * k2[i]) + (2.0 * k3[i] + k4[i]), s[i]);
 }
 
 template <> struct Env<REINMAV> {

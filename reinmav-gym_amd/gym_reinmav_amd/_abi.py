@@ -22,6 +22,7 @@ HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
 ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY, ACT_POLICY_BF16 = 0, 1, 2, 3, 4
 POLICY_FP32, POLICY_BF16_MFMA = 0, 1
+INT_EULER, INT_RK4 = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
 
@@ -45,7 +46,7 @@ class Params(C.Structure):
         ("vel_limit", C.c_double),
         ("thrust_scale", C.c_double),
         ("clamp_thrust", C.c_int32),
-        ("_pad", C.c_int32),
+        ("integrator", C.c_int32),
         ("ref_pos", C.c_double * 3),
         ("ref_vel", C.c_double * 3),
         ("kp", C.c_double),

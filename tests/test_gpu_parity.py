@@ -290,3 +290,26 @@ def test_full_size_properties(G, kind, n):
         assert scaled_err(tr["obs"][k][:, idx].T[alive], o2[alive]).max() <= TOL
         prev = tr["obs"][k][:, idx].T
     env.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_non_finite_inputs_follow_the_reference(G, kind):
+    """The reference has no NaN / inf guard: NaN propagates, `NaN > limit` is False so the env is
+    not done and the reward is -NaN; an infinite thrust terminates by |pos| = inf.  Same on the device."""
+    n = 256
+    s, a = random_cases(kind, n, seed=7, wide=False)
+    s *= 0.3
+    a_nan, a_inf = a.copy(), a.copy()
+    a_nan[::2, 0] = np.nan
+    a_inf[::2, 0] = np.inf
+    for act in (a_nan, a_inf):
+        env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
+        env.set_state(s)
+        obs, rew, done = env.step(act)
+        o2, r, d, _ = O.batch_step(kind, s.astype(np.float64), act.astype(np.float64))
+        assert np.array_equal(np.isnan(obs), np.isnan(o2)) and np.array_equal(np.isinf(obs), np.isinf(o2))
+        assert np.array_equal(done, d)
+        assert np.array_equal(np.isnan(rew), np.isnan(r))
+        fin = np.isfinite(o2).all(axis=1)
+        assert scaled_err(obs[fin], o2[fin]).max() <= TOL
+        env.close()

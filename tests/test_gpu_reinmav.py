@@ -112,3 +112,31 @@ def test_gym_shaped_reinmav_env(G, gold):
     obs, _, _, _ = env.step()
     assert scaled_err(obs, gold["run_s2"][100]).max() <= 3e-5   # input rounding, see above
     env.close()
+
+
+def test_rk4_option_vs_oracle_and_vs_euler(G, gold):
+    """RMAV_INT_RK4 (an option beyond the reference, which only has explicit Euler): matches the oracle's RK4,
+    and really is a different integrator than the default."""
+    A = G._abi
+    n = len(gold["step_s"])
+    p = A.default_params(A.REINMAV)
+    p.integrator = A.INT_RK4
+    s, t = gold["step_s"].astype(np.float32), gold["step_t"]
+    env = G.BatchedQuadrotor("reinmav", n, auto_reset=False, track_episodes=False, params=p)
+    env.set_state(s)
+    env.set_time(t)
+    obs = env.rollout(1, mode="controller", layout="aos", want=("obs",))["obs"][0]
+    exp, texp, _ = O.reinmav_batch_step(s.astype(np.float64), t, rk4=True)
+    assert scaled_err(obs, exp).max() <= TOL and np.array_equal(env.get_time(), texp)
+    euler, _, _ = O.reinmav_batch_step(s.astype(np.float64), t)
+    assert np.abs(exp - euler).max() > 1e-9
+    # on the reference's own (smooth) trajectory the two integrators agree closely at ds = 1/5000 s
+    k = 200
+    e1, _, _, _, _ = O.reinmav_step(gold["run_s"][k], gold["run_t"][k])
+    e4, _, _, _, _ = O.reinmav_step(gold["run_s"][k], gold["run_t"][k], rk4=True)
+    assert np.abs(e1 - e4).max() < 1e-3
+    bad = A.default_params(A.REINMAV)
+    bad.integrator = 7
+    with pytest.raises(G.RmavError):
+        G.BatchedQuadrotor("reinmav", 4, params=bad)
+    env.close()

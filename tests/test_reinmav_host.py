@@ -83,3 +83,19 @@ def test_kernel_arithmetic_on_host(gold, built):
     hm.hm_reinmav_step(C.byref(p), C.c_int64(len(s)), out.ctypes.data_as(fp), t.ctypes.data_as(dp), a.ctypes.data_as(fp),
                        fm0.ctypes.data_as(fp))
     assert scaled_err(out, exp).max() <= TOL and np.array_equal(fm0, a)
+
+
+def test_rk4_kernel_arithmetic_on_host(gold, built):
+    from gym_reinmav_amd import _abi as A
+
+    hm = C.CDLL(os.path.join(ROOT, "tests", "hostmath", "_build", "libhostmath.so"))
+    p = A.default_params(A.REINMAV)
+    p.integrator = A.INT_RK4
+    fp, dp = C.POINTER(C.c_float), C.POINTER(C.c_double)
+    s = gold["step_s"].astype(np.float32)
+    t = gold["step_t"].copy()
+    exp, texp, _ = O.reinmav_batch_step(s.astype(np.float64), t, rk4=True)
+    out, fm0 = s.copy(), np.zeros((len(s), 4), np.float32)
+    assert hm.hm_reinmav_step(C.byref(p), C.c_int64(len(s)), out.ctypes.data_as(fp), t.ctypes.data_as(dp), None,
+                              fm0.ctypes.data_as(fp)) == 0
+    assert scaled_err(out, exp).max() <= TOL and np.array_equal(t, texp)
