@@ -8,7 +8,7 @@ Workload (BASELINE.json configs[1], per GPU): quadrotor3d-v0, 65 536 envs, rando
 T~U[0,10), w~U[0,10)^3 drawn in-kernel from the counter RNG, auto-reset on done, episode tracking on.
 One bench "step" = ONE launch of the hot-path kernel over the whole batch:
 
-  --mode rollout (default): the fused rollout kernel advances every env ``--chunk`` (32) env-steps with the
+  --mode rollout (default): the fused rollout kernel advances every env ``--chunk`` (64) env-steps with the
       state held in registers and writes the full trajectory (actions, obs, reward, done per env-step)
       to HBM - the unit an RL learner consumes.
   --mode step: the same kernel at chunk = 1, one launch per env-step: actions read from a device buffer
@@ -88,12 +88,14 @@ def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kind", default="quad3d", choices=["quad2d", "quad2d_sl", "quad3d", "quad3d_sl"])
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
-    ap.add_argument("--chunk", type=int, default=32, help="env-steps per launch in rollout mode")
+    ap.add_argument("--chunk", type=int, default=64,
+                    help="env-steps per launch in rollout mode (64 amortises the ~4.5 us fixed cost of a launch; "
+                         "see profiles/*/sweep_kinds_sizes.md for 8..128)")
     ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other mode's short measurement")

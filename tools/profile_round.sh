@@ -16,7 +16,7 @@ run() {  # name, rocprof args..., -- cmd
   echo "rc=$? $(tail -1 $OUT/$name.log | cut -c1-300)"
 }
 # 1. kernel trace + stats of the exact default bench command (and of the step mode)
-run trace_rollout --kernel-trace --stats --output-format csv -d $OUT/trace_rollout -- $B --steps 200 --warmup 20
+run trace_rollout --kernel-trace --stats --output-format csv -d $OUT/trace_rollout -- $B --steps 100 --warmup 10
 run trace_step    --kernel-trace --stats --output-format csv -d $OUT/trace_step    -- $B --mode step --steps 2000 --warmup 50
 # 2. PMC passes: HBM-side bytes of the dominant kernel (per dispatch)
 for C in FETCH_SIZE WRITE_SIZE; do
