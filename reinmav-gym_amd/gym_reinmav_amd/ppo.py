@@ -297,8 +297,9 @@ class PPO:
 
     def __init__(self, policy: MlpPolicy, lr: float = 3e-4, clip: float = 0.2, epochs: int = 4, minibatches: int = 4,
                  vf_coef: float = 0.5, ent_coef: float = 0.0, max_grad_norm: float = 0.5, gamma: float = 0.99,
-                 lam: float = 0.95):
+                 lam: float = 0.95, reward_scale: float = 1.0):
         self.policy = policy
+        self.reward_scale = float(reward_scale)   # baselines' --reward_scale (gym_reinmav/run.py:76)
         self.opt = torch.optim.Adam(policy.parameters(), lr=lr, eps=1e-5)
         self.clip, self.epochs, self.minibatches = clip, epochs, minibatches
         self.vf_coef, self.ent_coef, self.max_grad_norm, self.gamma, self.lam = vf_coef, ent_coef, max_grad_norm, gamma, lam
@@ -318,7 +319,8 @@ class PPO:
 
     def update(self, ro: RolloutCollector) -> dict:
         T, N = ro.rew.shape
-        adv, ret = gae(ro.rew, ro.val, ro.done, self.gamma, self.lam)
+        rew = ro.rew if self.reward_scale == 1.0 else ro.rew * self.reward_scale
+        adv, ret = gae(rew, ro.val, ro.done, self.gamma, self.lam)
         obs = ro.obs[:T].permute(1, 0, 2).reshape(ro.obs.shape[1], T * N)   # [nS, T*N] feature-major
         act = ro.act.permute(1, 0, 2).reshape(ro.act.shape[1], T * N)
         logp_old, val_old = ro.logp.reshape(-1), ro.val[:T].reshape(-1)
