@@ -1,7 +1,7 @@
 /* rmav.h - C ABI of the MI355X-native batched quadrotor dynamics path (librmav.so).
  *
  * This is the drop-in boundary for reinmav-gym's native environments.  The reference has no FFI
- * (it is pure Python); what a binding replaces is the body of four gym.Env classes in
+ * (it is pure Python); what a binding replaces is the body of its five native gym.Env classes in
  * gym_reinmav/envs/native/ of the reference repository:
  *
  *   reference interface (file:line)                               entry point here
@@ -10,6 +10,8 @@
  *   Quadrotor3DSlungload.__init__   quadrotor3d_slungload.py:44-80  rmav_create(RMAV_QUAD3D_SL, ...)
  *   Quadrotor2D.__init__            quadrotor2d.py:43-67          rmav_create(RMAV_QUAD2D, ...)
  *   Quadrotor2DSlungload.__init__   quadrotor2d_slungload.py:43-73  rmav_create(RMAV_QUAD2D_SL, ...)
+ *   ReinmavEnv.__init__ / .step()   reinmav_env.py:53-84, 99-126  rmav_create(RMAV_REINMAV, ...),
+ *                                                                 rmav_rollout(RMAV_ACT_CONTROLLER), rmav_get_time
  *   (hard-coded physics literals in each __init__)                rmav_default_params / rmav_params
  *   .seed(seed)                     quadrotor3d.py:77-79          rmav_seed
  *   .reset()                        quadrotor3d.py:182-185        rmav_reset
@@ -25,6 +27,7 @@
  *                                   test/test_quadrotor3d.py:16-22
  *   baselines VecEnv rollouts driven by gym_reinmav/run.py:89,190-211
  *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM)
+ *   baselines ppo2 Runner.run(): model.step(obs) + env.step(a)    rmav_rollout_policy
  *   baselines Monitor episode statistics (info['episode'])        rmav_episode_totals / _buffers
  *
  * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
@@ -53,6 +56,8 @@
  *           quadrotor3d.py:184 draws every state component)
  *   action: c2 = low 32 bits of the handle's global step counter t,
  *           c3 = (2<<24) | (bits 32..47 of t) << 8 ; component i = fma(act_hi-act_lo, u_i, act_lo)
+ *   policy noise (rmav_rollout_policy): as "action" with tag 3; (r0,r1) and (r2,r3) -> Box-Muller:
+ *           u1 = ((r>>8)+1) * 2^-24, u2 = (r'>>8) * 2^-24, z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2)
  */
 #ifndef RMAV_H
 #define RMAV_H

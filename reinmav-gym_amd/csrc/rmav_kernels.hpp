@@ -8,13 +8,18 @@
 //   reset_cnt  u32 [N]       resets drawn so far (RNG counter); touched only on reset
 //   ep_ret/ep_len, last_ret/last_len   optional Monitor-style episode accumulators
 //   totals     {u64,f64,u64} [ceil(N/64)]  per-wavefront partial sums of finished episodes
+//   env_time   f64 [N]       RMAV_REINMAV only: each env's clock
+//   pe[3]      f32 [N]       optional per-env mass / load mass / tether length (domain randomisation)
 // Caller buffers: actions [T][nA][N] | [T][N][nA], obs [T][nS][N] | [T][N][nS], rew f32 [T][N],
 // done u8 [T][N].
 //
 // One kernel template covers step (n_steps = 1) and the fused rollout (n_steps = T, state held in
-// registers between steps, so per-step HBM traffic shrinks to actions-in + trajectory-out).
-// Per-step constants arrive as kernel arguments (scalar registers via s_load), not LDS: they are
-// wave-uniform, ~200 bytes, and an LDS copy would cost a barrier per launch for nothing.
+// registers between steps, so per-step HBM traffic shrinks to actions-in + trajectory-out).  The action
+// source is a template parameter: caller buffer, counter RNG, the reference's geometric controller, or a
+// Gaussian MLP policy evaluated in-kernel (fp32 VALU / bf16 MFMA).
+// Per-step physics constants arrive as kernel arguments (scalar registers via s_load), not LDS: they are
+// wave-uniform, ~200 bytes, and an LDS copy would cost a barrier per launch for nothing.  LDS is used where
+// the constants are too big for SGPRs: the policy weights (30-42 KB, staged once per launch).
 #pragma once
 
 #include "rmav_math.hpp"

@@ -1,4 +1,4 @@
-// rmav_math.hpp - per-env (per-lane) arithmetic of the batched quadrotor path, gfx950.
+// rmav_math.hpp - per-env (per-lane) arithmetic of the batched quadrotor path (five env kinds), gfx950.
 //
 // One environment lives in the registers of one wavefront lane; everything here is lane-local
 // register math (the 3x3 / quaternion products are ~100-250 flops, far below the HBM time of the
@@ -14,6 +14,7 @@
 //                           CDNA4 runs fp64 FMA at half the fp32 rate, which this HBM-bound path
 //                           does not notice.  sin/cos stay fp32 (|d| <= 6e-8 on a unit vector).
 //   controllers           : R = double (gains of 10..50 amplify fp32 rounding past 1e-6).
+//   reinmav               : R = double incl. asin/atan2/sincos (attitude loop gain kp_rot/I ~ 4e5 1/s^2).
 // All multiply-adds are written as explicit fma() and the library is built with
 // -ffp-contract=off, so the single-step kernel, the fused rollout kernel and the host test build
 // produce the same bits for the same inputs (up to libm's sinf/cosf/atan2).
