@@ -313,3 +313,49 @@ def test_non_finite_inputs_follow_the_reference(G, kind):
         fin = np.isfinite(o2).all(axis=1)
         assert scaled_err(obs[fin], o2[fin]).max() <= TOL
         env.close()
+
+
+@pytest.mark.parametrize("kind,n", [("quad3d", 65536), ("quad3d", 1048576)])
+def test_full_size_yaw_equivariance(G, kind, n):
+    """A size-independent property of the dynamics at BASELINE's full sizes: gravity is along z, so rotating the
+    world about z commutes with step():  step(Rz s, a) == Rz step(s, a)  (positions / velocities rotate, the
+    attitude quaternion is left-multiplied by the yaw quaternion, body rates and thrust are unchanged); reward and
+    done are invariant.  (Not a property of the slung-load envs: their tether force subtracts a scalar from a
+    vector, quadrotor3d_slungload.py:110, which singles out the coordinate axes - a quirk we reproduce.)"""
+    rng = np.random.RandomState(12)
+    env = G.BatchedQuadrotor(kind, n, seed=1, auto_reset=False, track_episodes=False)
+    s = env.get_state()                                   # U[-1,1) reset states
+    lo, hi = BOX[kind]
+    a = rng.uniform(lo, hi, (n, 4)).astype(np.float32)
+    psi = rng.uniform(-np.pi, np.pi, n)
+    c, sn = np.cos(psi), np.sin(psi)
+
+    def rot_vec(v):                                        # [n,3]
+        return np.stack([c * v[:, 0] - sn * v[:, 1], sn * v[:, 0] + c * v[:, 1], v[:, 2]], axis=1)
+
+    def rot_quat(q):                                       # q_yaw (x) q, q_yaw = (cos psi/2, 0, 0, sin psi/2)
+        cw, cz = np.cos(psi / 2), np.sin(psi / 2)
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        return np.stack([cw * w - cz * z, cw * x - cz * y, cw * y + cz * x, cw * z + cz * w], axis=1)
+
+    def rot_state(st):
+        st = st.astype(np.float64)
+        out = st.copy()
+        out[:, 0:3], out[:, 3:7], out[:, 7:10] = rot_vec(st[:, 0:3]), rot_quat(st[:, 3:7]), rot_vec(st[:, 7:10])
+        if kind == "quad3d_sl":
+            out[:, 10:13], out[:, 13:16] = rot_vec(st[:, 10:13]), rot_vec(st[:, 13:16])
+        return out
+
+    obs, rew, done = env.step(a)
+    s_rot = rot_state(s).astype(np.float32)
+    env.set_state(s_rot)
+    env.set_sbd(np.full(n, -1, np.int32))
+    obs_r, rew_r, done_r = env.step(a)
+    expect = rot_state(obs)
+    near = near_threshold(kind, obs.astype(np.float64), eps=1e-4)
+    assert np.array_equal(done | near, done_r | near)
+    # the rotated input is rounded to fp32 once more, so allow a few ulps of the state magnitude
+    assert scaled_err(obs_r, expect).max() < 2e-6
+    ok = ~near & ~done
+    assert np.abs(rew_r[ok] - rew[ok]).max() < 2e-6 * max(1.0, float(np.abs(rew[ok]).max()))
+    env.close()
