@@ -70,7 +70,7 @@ def test_quad2d_reading_A_vs_golden(G, golden):
 def test_step_vs_oracle_random_device_buffers(G, kind, layout):
     import torch
 
-    n = 50000 + 37  # ragged: not a multiple of the 256-thread block or the 64-lane wave
+    n = 1000000 + 37  # ragged: not a multiple of the 256-thread block or the 64-lane wave
     s, a = random_cases(kind, n, seed=101)
     env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
     env.set_state(s)
