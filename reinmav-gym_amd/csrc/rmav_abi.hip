@@ -130,16 +130,50 @@ int ensure_scratch(rmav_handle h, size_t bytes) {
     return RMAV_OK;
 }
 
-template <int K, int MODE>
-int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
+// Cache policy of the trajectory stores for one launch (thresholds measured, see rmav_kernels.hpp): bytes a launch
+// writes = n_steps * N * (4 nA [actions] + 4 nS [obs] + 4 [reward] + 1 [done]).  RMAV_STORE_POLICY=0|1|2 overrides.
+int pick_store_policy(rmav_handle h, const RolloutArgs &a) {
+    static const int forced = [] {
+        const char *e = getenv("RMAV_STORE_POLICY");
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced <= 2) return forced;
+    if (a.n_steps < 8 || (a.flags & F_AOS)) return ST_DEFAULT;
+    double per_step = 0.0;
+    if (a.act_out) per_step += 4.0 * kActionDim[h->kind];
+    if (a.obs_out) per_step += 4.0 * kStateDim[h->kind];
+    if (a.rew_out) per_step += 4.0;
+    if (a.done_out) per_step += 1.0;
+    const double bytes = per_step * (double)h->n * (double)a.n_steps;
+    if (bytes >= 768.0e6) return ST_STREAM;
+    if (bytes <= 320.0e6) return ST_WRITE_THROUGH;
+    return ST_DEFAULT;
+}
+
+template <int K, int MODE, int ST>
+int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                                                    : 0;
-    hipLaunchKernelGGL((k_rollout<K, MODE>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
+    hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
+}
+
+template <int K, int MODE>
+int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
+    // the policy modes are compute-bound: one instantiation is enough there
+    if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
+        return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
+    } else {
+        switch (pick_store_policy(h, a)) {
+        case ST_WRITE_THROUGH: return launch_rollout_kms<K, MODE, ST_WRITE_THROUGH>(h, a);
+        case ST_STREAM: return launch_rollout_kms<K, MODE, ST_STREAM>(h, a);
+        default: return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
+        }
+    }
 }
 
 template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs &a) {

@@ -100,10 +100,27 @@ __device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t sof
     __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, r, voff, soff, 0);
 }
 
-template <int K, int MODE>
+// Cache policy of the SoA trajectory stores - a template parameter because the policy bits are instruction
+// immediates (a wave-uniform runtime switch around three copies of the stores measured 9 % SLOWER than no
+// choice at all: code size and SGPR pressure in the step loop).  Measured, 64-step quadrotor3d rollouts:
+//   ST_WRITE_THROUGH (sc0 sc1): the line leaves the L2 at once.  Best when one launch's trajectory is small
+//       (65 536 envs: 65.3 -> 62.5 us): nothing is left dirty for the end-of-kernel L2 write-back.
+//   ST_STREAM (nt): best when one launch writes more than the 256 MB Infinity Cache absorbs
+//       (262 144 envs: 232 -> 206 us, 1 M envs: 892 -> 772 us).
+//   ST_DEFAULT in between and for single-step launches.
+enum : int { ST_DEFAULT = 0, ST_WRITE_THROUGH = 1, ST_STREAM = 2 };
+template <int ST> struct StoreAux { static constexpr int value = (ST == ST_WRITE_THROUGH) ? 17 : (ST == ST_STREAM ? 2 : 0); };
+
+template <int AUX>
+__device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, AUX);
+}
+
+template <int K, int MODE, int ST = ST_DEFAULT>
 __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
+    constexpr int AUX = StoreAux<ST>::value;
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
@@ -292,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 } else {
                     const rsrc_t ra = make_rsrc(act_out);
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) buf_st(ra, off, (uint32_t)c * col, act[c]);
+                    for (int c = 0; c < NA; ++c) buf_st_aux<AUX>(ra, off, (uint32_t)c * col, act[c]);
                 }
                 act_out += (int64_t)NA * n;
             }
@@ -330,12 +347,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 } else {
                     const rsrc_t ro = make_rsrc(obs_out);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
+                    for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * col, s[c]);
                 }
                 obs_out += (int64_t)NS * n;
             }
             if (rew_out) {
-                buf_st(make_rsrc(rew_out), off, 0, r);
+                buf_st_aux<AUX>(make_rsrc(rew_out), off, 0, r);
                 rew_out += n;
             }
             if (done_out) {

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librmav.so")
+LIB_PATH = os.environ.get("RMAV_LIB_PATH") or os.path.join(_HERE, "librmav.so")   # override: A/B builds only
 
 # enums of include/rmav.h
 QUAD2D, QUAD2D_SL, QUAD3D, QUAD3D_SL, REINMAV = 0, 1, 2, 3, 4
