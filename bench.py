@@ -279,6 +279,18 @@ def main():
                     if best is None or r["value"] > best["value"]:
                         best = r
                 line["cpu_baseline_multithread"] = best
+            # interpreter-bound stand-in for the reference's own Python (which cannot travel to this box):
+            # a per-env NumPy restatement in the reference's style (oracle/numpy_ref.py), ~2 s sample
+            try:
+                import numpy_ref
+
+                v, k, el = numpy_ref.time_steps(min(2.0, args.cpu_seconds))
+                line["cpu_baseline_python"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                               "sample": f"per-env NumPy restatement of Quadrotor3D.step, {k} env-steps, "
+                                                         f"{el:.1f} s, 1 process (the reference itself ran at 16.1 k "
+                                                         "env-steps/s in the authoring container, BASELINE.md section 2)"}
+            except Exception as e:  # pragma: no cover
+                line["cpu_baseline_python"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     env.close()
     if use_dist:

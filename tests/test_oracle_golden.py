@@ -152,3 +152,20 @@ def test_oracle_vs_live_reference(built):
             o, r, d, _ = O.step(kind, s, a)
             assert scaled_err(o, o_ref).max() < FP64_TOL and abs(r - r_ref) < FP64_TOL and d == d_ref
             assert scaled_err(O.control(kind, s), c_ref).max() < 1e-11
+
+
+def test_numpy_per_env_restatement_matches_golden(golden, built):
+    """The per-env NumPy stand-in (oracle/numpy_ref.py, used as the interpreter-bound CPU baseline) against the
+    reference's golden vectors and the C oracle."""
+    from numpy_ref import Quadrotor3DNumpy
+
+    g = golden["quad3d"]
+    env = Quadrotor3DNumpy()
+    for i in range(0, len(g["step_s"]), 3):
+        env.state, env.steps_beyond_done = g["step_s"][i].copy(), None
+        o, r, d, _ = env.step(g["step_a"][i])
+        assert scaled_err(o, g["step_s2"][i]).max() < FP64_TOL and abs(r - g["step_r"][i]) < FP64_TOL and d == g["step_d"][i]
+    for i in range(0, len(g["ctrl_s"]), 3):
+        env.state = g["ctrl_s"][i].copy()
+        assert scaled_err(env.control(), g["ctrl_a"][i]).max() < 1e-11
+        assert scaled_err(env.control(), O.control("quad3d", g["ctrl_s"][i])).max() < 1e-11
