@@ -202,7 +202,7 @@ def main():
 
         wall, kernel_ms, per_launch = measure(args.mode, args.chunk, args.steps, args.warmup)
         secondary = None
-        if not args.no_secondary:
+        if not args.no_secondary:   # the other mode, for the record (every rank runs it: it contains collectives)
             other = "step" if args.mode == "rollout" else "rollout"
             K2 = 2000 if other == "step" else 100
             w2, k2, pl2 = measure(other, args.chunk, K2, 50 if other == "step" else 5)
@@ -266,7 +266,7 @@ def main():
         }
         if secondary:
             line["other_mode"] = secondary
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and kind != "reinmav":
             line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             if ncpu > 1:
