@@ -90,7 +90,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--kind", default="quad3d", choices=["quad2d", "quad2d_sl", "quad3d", "quad3d_sl"])
+    ap.add_argument("--kind", default="quad3d", choices=["quad2d", "quad2d_sl", "quad3d", "quad3d_sl", "reinmav"])
+    ap.add_argument("--actions", default="random", choices=["random", "controller"],
+                    help="action source of the fused rollout (controller = the reference's built-in / geometric controller)")
     ap.add_argument("--envs-per-gpu", type=int, default=65536)
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--chunk", type=int, default=64,
@@ -153,7 +155,7 @@ def main():
 
                 def run(k):
                     for _ in range(k):
-                        env.rollout(chunk, mode="random", layout=args.layout, fused=True,
+                        env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
                                     want=("actions", "obs", "rew", "done"), device_out=True, out=bufs)
                 return run, chunk
             # step mode: one launch per env-step; the launch loop runs inside librmav (rmav_rollout with
@@ -239,9 +241,9 @@ def main():
             "dtype": "f32" if kind in ("quad2d", "quad3d") else "f64 arithmetic on f32 storage",
             "data": "synthetic",
             "config": {
-                "workload": (f"{ {'quad3d': 'quadrotor3d-v0', 'quad3d_sl': 'quadrotor3d-slungload-v0', 'quad2d': 'quadrotor2d-v0', 'quad2d_sl': 'quadrotor2d-slungload-v0'}[kind]}"
+                "workload": (f"{ {'quad3d': 'quadrotor3d-v0', 'quad3d_sl': 'quadrotor3d-slungload-v0', 'quad2d': 'quadrotor2d-v0', 'quad2d_sl': 'quadrotor2d-slungload-v0', 'reinmav': 'reinmav-v0'}[kind]}"
                              f", {n} envs per GPU, random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
-                             + (f"one step = one fused rollout launch = {per_launch} env-steps per env, in-kernel action RNG, "
+                             + (f"one step = one fused rollout launch = {per_launch} env-steps per env, in-kernel action source '{args.actions}', "
                                 "trajectory (actions, obs, reward, done) written to HBM" if args.mode == "rollout"
                                 else "one step = one launch = 1 env-step per env, actions read from a device buffer, "
                                      "obs/reward/done written")),

@@ -495,7 +495,12 @@ __global__ __launch_bounds__(kBlock) void k_control_reinmav(const float *state, 
     double s[13], fm[4];
 #pragma unroll
     for (int c = 0; c < 13; ++c) s[c] = state[(int64_t)c * n + i];
-    reinmav_controller(p, s, env_time[i], fm);
+    double R[3][3];
+    {
+        const double q[4] = {s[6], s[7], s[8], s[9]};
+        reinmav_quat2mat(q, R);
+    }
+    reinmav_controller(p, s, R, env_time[i], fm);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (flags & F_AOS) act_out[i * 4 + c] = (float)fm[c];

@@ -479,14 +479,16 @@ RMAV_HD void reinmav_quat2mat(const double (&q)[4], double (&m)[3][3]) {   // qu
 }
 
 // trj_gen (:128-136) + stateToQd / RotToRPY (:292-304, :341-346) + controller (:306-337) -> (F, Mx, My, Mz)
-RMAV_HD void reinmav_controller(const ReinmavP &p, const double (&s)[13], double t, double (&fm)[4]) {
-    double R[3][3];
-    const double q[4] = {s[6], s[7], s[8], s[9]};
-    reinmav_quat2mat(q, R);
+// R = quat2mat(attitude) is passed in: the controller and the dynamics of one sub-step use the same matrix.
+RMAV_HD void reinmav_controller(const ReinmavP &p, const double (&s)[13], const double (&R)[3][3], double t,
+                                double (&fm)[4]) {
+    // RotToRPY :341-346.  phi = asin(R12) lies in [-pi/2, pi/2], so cos(phi) = sqrt(1 - R12^2) >= 0, and dividing
+    // both atan2 arguments by that positive number (as the reference does) does not change the angle: the two
+    // divisions and the cos() are dropped (differences at the 1e-16 level, far below the 1e-6 parity bar; at
+    // cos(phi) == 0 the reference divides by zero and returns NaN/pi/2 - a gimbal-lock state it never reaches).
     const double phi = asin(R[1][2]);
-    const double cphi = cos(phi);
-    const double psi = atan2(-R[1][0] / cphi, R[1][1] / cphi);
-    const double theta = atan2(-R[0][2] / cphi, R[2][2] / cphi);
+    const double psi = atan2(-R[1][0], R[1][1]);
+    const double theta = atan2(-R[0][2], R[2][2]);
     const double tm = p.t_max;
     double u = t < tm ? t : tm;
     u = (u > 0.0 ? u : 0.0) / tm;
@@ -509,7 +511,8 @@ RMAV_HD void reinmav_controller(const ReinmavP &p, const double (&s)[13], double
 }
 
 // quad_eq_of_motion2 (:203-264): sdot = f(s, F, M)
-RMAV_HD void reinmav_derivative(const ReinmavP &p, const double (&s)[13], const double (&fm)[4], double (&sd)[13]) {
+RMAV_HD void reinmav_derivative(const ReinmavP &p, const double (&s)[13], const double (&bRw)[3][3], const double (&fm)[4],
+                                double (&sd)[13]) {
     const double L = p.arm_length, k = 0.5 / L;
     double T[4] = {0.25 * fm[0] - k * fm[2], 0.25 * fm[0] + k * fm[1], 0.25 * fm[0] + k * fm[2], 0.25 * fm[0] - k * fm[1]};
 #pragma unroll
@@ -520,8 +523,6 @@ RMAV_HD void reinmav_derivative(const ReinmavP &p, const double (&s)[13], const 
     const double force = T[0] + T[1] + T[2] + T[3];
     const double mom[3] = {L * T[1] - L * T[3], L * T[2] - L * T[0], fm[3]};
     const double q[4] = {s[6], s[7], s[8], s[9]};
-    double bRw[3][3];
-    reinmav_quat2mat(q, bRw);
     const double im = 1.0 / p.mass;
     const double acc[3] = {im * (bRw[2][0] * force), im * (bRw[2][1] * force), im * (bRw[2][2] * force - p.mass * p.gravity)};
     const double pw = s[10], qw = s[11], rw = s[12];
@@ -548,10 +549,10 @@ RMAV_HD void reinmav_derivative(const ReinmavP &p, const double (&s)[13], const 
 }
 
 // one sub-step of length ds with the command held:  explicit Euler (the reference, :98) or classical RK4
-RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&fm)[4]) {
+RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&R)[3][3], const double (&fm)[4]) {
     const double ds = p.ds;
     double k1[13];
-    reinmav_derivative(p, s, fm, k1);
+    reinmav_derivative(p, s, R, fm, k1);
     if (!p.rk4) {
 #pragma unroll
         for (int i = 0; i < 13; ++i) s[i] = rfma(ds, k1[i], s[i]);
@@ -560,13 +561,26 @@ RMAV_HD void reinmav_substep(const ReinmavP &p, double (&s)[13], const double (&
     double k2[13], k3[13], k4[13], y[13];
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = rfma(0.5 * ds, k1[i], s[i]);
-    reinmav_derivative(p, y, fm, k2);
+    double Ry[3][3];
+    {
+        const double qy[4] = {y[6], y[7], y[8], y[9]};
+        reinmav_quat2mat(qy, Ry);
+    }
+    reinmav_derivative(p, y, Ry, fm, k2);
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = rfma(0.5 * ds, k2[i], s[i]);
-    reinmav_derivative(p, y, fm, k3);
+    {
+        const double qy[4] = {y[6], y[7], y[8], y[9]};
+        reinmav_quat2mat(qy, Ry);
+    }
+    reinmav_derivative(p, y, Ry, fm, k3);
 #pragma unroll
     for (int i = 0; i < 13; ++i) y[i] = rfma(ds, k3[i], s[i]);
-    reinmav_derivative(p, y, fm, k4);
+    {
+        const double qy[4] = {y[6], y[7], y[8], y[9]};
+        reinmav_quat2mat(qy, Ry);
+    }
+    reinmav_derivative(p, y, Ry, fm, k4);
 #pragma unroll
     for (int i = 0; i < 13; ++i) s[i] = rfma(ds / 6.0, (k1[i] + 2.0 * k2[i]) + (2.0 * k3[i] + k4[i]), s[i]);
 }
@@ -587,15 +601,20 @@ template <> struct Env<REINMAV> {
         const double delta = (start + p.ds) - start;
         double fm[4] = {a[0], a[1], a[2], a[3]};
         for (int i = 0; i < n; ++i) {
+            double R[3][3];
+            {
+                const double q[4] = {s[6], s[7], s[8], s[9]};
+                reinmav_quat2mat(q, R);
+            }
             if (use_controller) {
                 const double ti = (i == 0) ? start : ((i == 1) ? start + p.ds : start + i * delta);
-                reinmav_controller(p, s, ti, fm);
+                reinmav_controller(p, s, R, ti, fm);
             }
             if (i == 0) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) fm0[c] = (float)fm[c];
             }
-            reinmav_substep(p, s, fm);
+            reinmav_substep(p, s, R, fm);
         }
         t = t + p.dt;   // :119
 #pragma unroll
