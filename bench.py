@@ -250,6 +250,7 @@ def main():
                 "envs_per_gpu": n,
                 "env_steps_per_launch_per_env": per_launch,
                 "mode": args.mode,
+                "trajectory_layout": args.layout if args.mode == "rollout" else "soa",
                 "parallelism": f"env-shard x{world} (global env ids; one RCCL all-gather of episode stats per timed region)"
                 if world > 1 else "single GPU",
                 "finished_episodes": totals["episodes"],

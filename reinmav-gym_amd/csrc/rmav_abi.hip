@@ -137,14 +137,19 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a) {
         const char *e = getenv("RMAV_STORE_POLICY");
         return e ? atoi(e) : -1;
     }();
-    if (forced >= 0 && forced <= 2) return forced;
-    if (a.n_steps < 8 || (a.flags & F_AOS)) return ST_DEFAULT;
+    if (forced >= 0 && forced <= 2 && !(a.flags & F_AOS)) return forced;
+    if (a.n_steps < 8) return ST_DEFAULT;
     double per_step = 0.0;
     if (a.act_out) per_step += 4.0 * kActionDim[h->kind];
     if (a.obs_out) per_step += 4.0 * kStateDim[h->kind];
     if (a.rew_out) per_step += 4.0;
     if (a.done_out) per_step += 1.0;
     const double bytes = per_step * (double)h->n * (double)a.n_steps;
+    if (a.flags & F_AOS) {   // batch-major trajectories: LDS-transposed obs stores once the launch is big (RMAV_STORE_POLICY=3: always, 0: never)
+        if (forced == 0) return ST_DEFAULT;
+        // measured (profiles/r01/layout_sweep.md): pays from 131 072 envs x 64 steps (512 MB), costs 10-15 % at 65 536 (256 MB)
+        return (a.obs_out && (bytes >= 448.0e6 || forced == ST_AOS_LDS)) ? ST_AOS_LDS : ST_DEFAULT;
+    }
     if (bytes >= 768.0e6) return ST_STREAM;
     if (bytes <= 320.0e6) return ST_WRITE_THROUGH;
     return ST_DEFAULT;
@@ -156,6 +161,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     const ParamsT<double> pc = derive<double>(h->params);
     const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
+                       : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
     hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
@@ -171,6 +177,7 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
         switch (pick_store_policy(h, a)) {
         case ST_WRITE_THROUGH: return launch_rollout_kms<K, MODE, ST_WRITE_THROUGH>(h, a);
         case ST_STREAM: return launch_rollout_kms<K, MODE, ST_STREAM>(h, a);
+        case ST_AOS_LDS: return launch_rollout_kms<K, MODE, ST_AOS_LDS>(h, a);
         default: return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
         }
     }

@@ -108,8 +108,17 @@ __device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t sof
 //   ST_STREAM (nt): best when one launch writes more than the 256 MB Infinity Cache absorbs
 //       (262 144 envs: 232 -> 206 us, 1 M envs: 892 -> 772 us).
 //   ST_DEFAULT in between and for single-step launches.
-enum : int { ST_DEFAULT = 0, ST_WRITE_THROUGH = 1, ST_STREAM = 2 };
-template <int ST> struct StoreAux { static constexpr int value = (ST == ST_WRITE_THROUGH) ? 17 : (ST == ST_STREAM ? 2 : 0); };
+//   ST_AOS_LDS: big launches that want the obs trajectory as [T][N][nS] (gym / torch batch-major tensors).  A
+//       lane storing its own nS floats touches every 128-byte line of the wavefront's 64 x nS x 4 byte span
+//       once per component (40 / 64 byte lane stride: 1 M envs 21 % (quadrotor3d) / 32 % (slung load) slower
+//       than SoA).  Here each full wavefront transposes its obs tile through LDS (row stride nS | 1 words:
+//       conflict-free writes) and emits it as nS fully coalesced 256-byte `nt` stores.
+enum : int { ST_DEFAULT = 0, ST_WRITE_THROUGH = 1, ST_STREAM = 2, ST_AOS_LDS = 3 };
+template <int ST> struct StoreAux {
+    static constexpr int value = (ST == ST_WRITE_THROUGH) ? 17 : ((ST == ST_STREAM || ST == ST_AOS_LDS) ? 2 : 0);
+};
+// LDS words per wavefront of the ST_AOS_LDS obs tile
+template <int NS> struct AosTile { static constexpr int STRIDE = NS | 1, WORDS = 64 * STRIDE; };
 
 template <int AUX>
 __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t soff, float v) {
@@ -197,6 +206,26 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         if (K != REINMAV && auto_reset && a.n_steps >= 8) {   // ReinmavEnv.reset() is a no-op (reinmav_env.py:348-351)
             reset_state<K>(a.seed, env_id, rc, spare);
             have_spare = true;
+        }
+
+        // ST_AOS_LDS: this wavefront's transposition tile and, per output dword j of the lane, where in the
+        // tile the element lives (output element e = 64 j + lane is component e % NS of the wave's env e / NS)
+        [[maybe_unused]] float *tile = nullptr;
+        [[maybe_unused]] uint32_t tile_rd[NS];
+        [[maybe_unused]] bool full_wave = false;
+        [[maybe_unused]] uint32_t wave_obs_base = 0;
+        if constexpr (ST == ST_AOS_LDS) {
+            const uint32_t lane = threadIdx.x & 63u;
+            // readfirstlane: tell the compiler these are wave-uniform (SGPR offsets, no waterfall loops)
+            const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
+            tile = lds_w + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * AosTile<NS>::WORDS;
+            full_wave = (uint64_t)wave_first + 64u <= (uint64_t)n;
+            wave_obs_base = wave_first * (uint32_t)(NS * 4);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                const uint32_t e = 64u * j + lane;
+                tile_rd[j] = (e / NS) * AosTile<NS>::STRIDE + (e % NS);
+            }
         }
 
         // uniform cursors into the time-major trajectory buffers, advanced once per step
@@ -314,10 +343,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
             }
             if (act_out) {
-                if (aos) {
+                if (aos) {   // 8 / 16 bytes per lane, contiguous across the wavefront: already coalesced
                     float *dst = act_out + (int64_t)li * NA;
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) dst[c] = act[c];
+                    for (int c = 0; c < NA; ++c) {
+                        if constexpr (ST == ST_AOS_LDS) __builtin_nontemporal_store(act[c], dst + c);
+                        else dst[c] = act[c];
+                    }
                 } else {
                     const rsrc_t ra = make_rsrc(act_out);
 #pragma unroll
@@ -352,7 +384,22 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 rc += 1;
             }
             if (obs_out) {
-                if (aos) {
+                if (ST == ST_AOS_LDS && full_wave) {
+                    // all 64 lanes are here (full_wave is wave-uniform); LDS executes one wavefront's
+                    // instructions in order, the fences only pin the compiler's ordering
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    float *row = tile + (threadIdx.x & 63u) * AosTile<NS>::STRIDE;
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) row[c] = s[c];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const rsrc_t ro = make_rsrc(obs_out);
+                    const uint32_t voff = (threadIdx.x & 63u) * 4u;
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) buf_st_aux<AUX>(ro, voff, wave_obs_base + 256u * j, tile[tile_rd[j]]);
+                } else if (aos) {
                     float *dst = obs_out + (int64_t)li * NS;
 #pragma unroll
                     for (int c = 0; c < NS; ++c) dst[c] = s[c];

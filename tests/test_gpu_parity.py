@@ -292,6 +292,49 @@ def test_full_size_properties(G, kind, n):
     env.close()
 
 
+def test_fused_trajectory_larger_than_4_GiB(G):
+    """One fused launch whose obs trajectory is 4.5 GiB (1 M slung-load envs x 72 steps): the per-step
+    output pointers advance in 64-bit arithmetic (only the offset inside one step is 32-bit).  The tail
+    of the big launch must equal a second handle that reaches the same steps through a small launch."""
+    import torch
+
+    kind, n, T, T1 = "quad3d_sl", 1 << 20, 72, 64
+    big = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=False)
+    tr = big.rollout(T, mode="random", layout="soa", want=("obs", "rew", "done"), device_out=True)
+    assert tr["obs"].numel() * 4 > (1 << 32)
+    ref = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=False)
+    ref.rollout(T1, mode="random", want=())
+    tail = ref.rollout(T - T1, mode="random", layout="soa", want=("obs", "rew", "done"), device_out=True)
+    for key in ("obs", "rew", "done"):
+        assert torch.equal(tr[key][T1:], tail[key]), key
+    assert torch.equal(tr["obs"][-1], big.get_state(layout="soa", device_out=True))
+    assert bool(torch.isfinite(tr["rew"]).all())
+    big.close()
+    ref.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_batch_major_trajectory_of_a_big_launch(G, kind):
+    """A launch that writes > 768 MB with layout='aos' takes the LDS-transposed obs stores (full wavefronts)
+    plus the direct path for the ragged last wavefront: its [T][N][nS] trajectory must be the [T][nS][N] one
+    transposed, bit for bit."""
+    import torch
+
+    n, T = (1 << 19) + 37, 64
+    out = {}
+    for layout in ("soa", "aos"):
+        env = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
+        out[layout] = env.rollout(T, mode="random", layout=layout, want=("actions", "obs", "rew", "done"), device_out=True)
+        out[layout]["state"] = env.get_state(layout="soa", device_out=True)
+        env.close()
+    soa, aos = out["soa"], out["aos"]
+    assert aos["obs"].shape == (T, n, NS[kind])
+    assert torch.equal(aos["obs"], soa["obs"].transpose(1, 2))
+    assert torch.equal(aos["actions"], soa["actions"].transpose(1, 2))
+    assert torch.equal(aos["rew"], soa["rew"]) and torch.equal(aos["done"], soa["done"])
+    assert torch.equal(aos["state"], soa["state"])
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_non_finite_inputs_follow_the_reference(G, kind):
     """The reference has no NaN / inf guard: NaN propagates, `NaN > limit` is False so the env is
