@@ -9,7 +9,6 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
-import numpy as np
 
 try:
     import torch

@@ -25,8 +25,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 
 def arg_parser():
     p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)

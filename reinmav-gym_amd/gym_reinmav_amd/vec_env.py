@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import _abi as A
 from .core import BatchedQuadrotor, torch
 from .spaces import Box
 

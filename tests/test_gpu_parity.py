@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from util import BOX, CTRL_TOL, KINDS, NA, NS, TERM, TOL, near_threshold, random_cases, scaled_err
+from util import BOX, CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, random_cases, scaled_err
 
 pytestmark = pytest.mark.gpu
 
