@@ -103,6 +103,8 @@ int check_params(const rmav_params &q) {
 inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
 
 // Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
+constexpr int64_t kSplitMaxEnvs = 131072;   // measured: see DESIGN.md section 4
+
 int block_size() {
     static int b = [] {
         const char *e = getenv("RMAV_BLOCK");
@@ -163,9 +165,26 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
-    hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
+    if constexpr (MODE == ACT_RANDOM_SPLIT) {   // two wavefronts (integrator + action producer) per 64 envs
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + 63) / 64)), dim3(128),
+                           sizeof(float) * SplitTile<Dims<K>::NA>::WORDS, h->stream, a, p, pc);
+    } else {
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
+    }
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
+}
+
+// Random-action rollouts of small batches run with the action draws on a second wavefront (ACT_RANDOM_SPLIT in
+// rmav_kernels.hpp): it pays while the batch leaves SIMDs under-occupied.  RMAV_SPLIT=0|1 overrides.
+bool use_split(rmav_handle h, const RolloutArgs &a, int st) {
+    static const int forced = [] {
+        const char *e = getenv("RMAV_SPLIT");
+        return e ? atoi(e) : -1;
+    }();
+    if (a.n_steps < 8 || st == ST_AOS_LDS) return false;
+    if (forced == 0 || forced == 1) return forced == 1;
+    return h->n <= kSplitMaxEnvs;
 }
 
 template <int K, int MODE>
@@ -174,7 +193,18 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
         return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
     } else {
-        switch (pick_store_policy(h, a)) {
+        const int st = pick_store_policy(h, a);
+        // fp32 kinds only: measured +4..8 % at <= 131 072 envs; the fp64 slung-load kinds gain < 1 % at 65 536 and lose above
+        if constexpr (MODE == ACT_RANDOM && (K == QUAD2D || K == QUAD3D)) {
+            if (use_split(h, a, st)) {
+                switch (st) {
+                case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_WRITE_THROUGH>(h, a);
+                case ST_STREAM: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_STREAM>(h, a);
+                default: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_DEFAULT>(h, a);
+                }
+            }
+        }
+        switch (st) {
         case ST_WRITE_THROUGH: return launch_rollout_kms<K, MODE, ST_WRITE_THROUGH>(h, a);
         case ST_STREAM: return launch_rollout_kms<K, MODE, ST_STREAM>(h, a);
         case ST_AOS_LDS: return launch_rollout_kms<K, MODE, ST_AOS_LDS>(h, a);

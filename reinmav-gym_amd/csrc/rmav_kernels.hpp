@@ -28,7 +28,12 @@
 
 namespace rmav {
 
-enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4 };
+enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4,
+              // internal: ACT_RANDOM with the action draws on a second wavefront of the workgroup (see k_rollout)
+              ACT_RANDOM_SPLIT = 5 };
+// ACT_RANDOM_SPLIT: env-steps drawn per hand-over, and the LDS words of the double-buffered action tile
+constexpr int kSplitChunk = 4;
+template <int NA> struct SplitTile { static constexpr int HALF = kSplitChunk * NA * 64, WORDS = 2 * HALF; };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
 constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
@@ -130,13 +135,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
+    const uint32_t gi = (MODE == ACT_RANDOM_SPLIT) ? blockIdx.x * 64u + (threadIdx.x & 63u)
+                                                   : blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
     // exactly what that env's lane does; only the episode totals must not count them.
     const bool valid = gi < (uint64_t)n;
-    const uint32_t li = (MODE == ACT_POLICY_BF16 && !valid) ? (uint32_t)n - 1u : gi;   // local env index
+    const uint32_t li = ((MODE == ACT_POLICY_BF16 || MODE == ACT_RANDOM_SPLIT) && !valid) ? (uint32_t)n - 1u : gi;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
@@ -145,6 +152,49 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
+
+    // ACT_RANDOM_SPLIT.  At C2 (65 536 envs = one wavefront per SIMD) the fused kernel is bound by how fast ONE
+    // wavefront can issue instructions (~5 cycles each, VALU + SALU + branches in one stream: 0.72 us per
+    // env-step without any store, against 0.34 us per wavefront-step when 16 wavefronts share a SIMD), and a
+    // third of that stream is the Philox draw of the next action - work that does not depend on the state.
+    // So the workgroup gets a second wavefront for the same 64 envs: it draws kSplitChunk env-steps of actions
+    // ahead into a double-buffered LDS tile (and writes the action trajectory), the first wavefront integrates.
+    // Two instruction streams per SIMD instead of one; one s_barrier per kSplitChunk env-steps.  Same counters,
+    // same bits as ACT_RANDOM.  Lanes past the end of the batch are clones of env N-1 (as in the MFMA mode) so
+    // that every lane of both wavefronts reaches every barrier.
+    if constexpr (MODE == ACT_RANDOM_SPLIT) {
+        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1u) {
+            const uint64_t env_id = a.env_base + (uint64_t)li;
+            const uint32_t lane = threadIdx.x & 63u;
+            float *act_out = a.act_out;
+            for (int32_t k0 = 0; k0 < a.n_steps; k0 += kSplitChunk) {
+                float *buf = lds_w + ((k0 / kSplitChunk) & 1) * SplitTile<NA>::HALF + lane;
+#pragma unroll
+                for (int j = 0; j < kSplitChunk; ++j) {
+                    if (k0 + j < a.n_steps) {
+                        float act[NA];
+                        random_action<K>(a.seed, env_id, a.t0 + (uint64_t)(k0 + j), a.act_lo, a.act_hi, act);
+#pragma unroll
+                        for (int c = 0; c < NA; ++c) buf[(j * NA + c) * 64] = act[c];
+                        if (act_out) {
+                            if (aos) {
+                                float *dst = act_out + (int64_t)li * NA;
+#pragma unroll
+                                for (int c = 0; c < NA; ++c) dst[c] = act[c];
+                            } else {
+                                const rsrc_t ra = make_rsrc(act_out);
+#pragma unroll
+                                for (int c = 0; c < NA; ++c) buf_st_aux<AUX>(ra, off, (uint32_t)c * col, act[c]);
+                            }
+                            act_out += (int64_t)NA * n;
+                        }
+                    }
+                }
+                __syncthreads();   // hand-over k0 / kSplitChunk
+            }
+            return;
+        }
+    }
 
     // ACT_POLICY: stage the policy weights into LDS once per launch (every thread of the block helps)
     if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
@@ -230,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 
         // uniform cursors into the time-major trajectory buffers, advanced once per step
         const float *act_in = a.act_in;
-        float *act_out = (MODE != ACT_BUFFER) ? a.act_out : nullptr;
+        float *act_out = (MODE != ACT_BUFFER && MODE != ACT_RANDOM_SPLIT) ? a.act_out : nullptr;   // SPLIT: the producer writes them
         float *obs_out = a.obs_out;
         float *rew_out = a.rew_out;
         uint8_t *done_out = a.done_out;
@@ -314,6 +364,12 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 if (k + 1 < a.n_steps) load_actions(act_in, act_pre);
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
+            } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
+                if ((k % kSplitChunk) == 0) __syncthreads();   // the producer has filled tile half (k / chunk) & 1
+                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NA>::HALF +
+                                   (k % kSplitChunk) * (NA * 64) + (threadIdx.x & 63u);
+#pragma unroll
+                for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
             } else if constexpr (K == REINMAV) {
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = 0.0f;   // the built-in controller runs inside every sub-step

@@ -57,9 +57,13 @@ def test_two_processes_equal_one(tmp_path, built):
     assert [int(p["start"]) for p in parts] == [0, 10001]
     for key in ("obs", "rew", "done"):
         assert np.array_equal(np.concatenate([p[key] for p in parts], axis=-1), tr[key]), key
-    for p in parts:   # every rank holds the same gathered statistics, equal to the unsharded run
-        assert np.array_equal(p["rets"], eb["last_return"]) and np.array_equal(p["lens"], eb["last_length"])
-        assert p["tot"][0] == tot["episodes"] and p["tot"][2] == tot["length_sum"]
-        assert abs(p["tot"][1] - tot["return_sum"]) <= 1e-6 * abs(tot["return_sum"]) + 1e-3
-    assert tot["episodes"] > 0
+    for r, p in enumerate(parts):   # every rank holds the same gathered statistics, equal to the unsharded run
+        bad = np.flatnonzero(p["rets"] != eb["last_return"])
+        assert bad.size == 0, f"rank {r}: last_return differs at envs {bad[:8]}: {p['rets'][bad[:8]]} vs {eb['last_return'][bad[:8]]}"
+        bad = np.flatnonzero(p["lens"] != eb["last_length"])
+        assert bad.size == 0, f"rank {r}: last_length differs at envs {bad[:8]}: {p['lens'][bad[:8]]} vs {eb['last_length'][bad[:8]]}"
+        assert p["tot"][0] == tot["episodes"] and p["tot"][2] == tot["length_sum"], f"rank {r}: totals {p['tot']} vs {tot}"
+        assert abs(p["tot"][1] - tot["return_sum"]) <= 1e-6 * abs(tot["return_sum"]) + 1e-3, f"rank {r}: totals {p['tot']} vs {tot}"
+    assert tot["episodes"] > 0, tot
+    assert tot["episodes"] == int(tr["done"].sum()), (tot, int(tr["done"].sum()))
     full.close()

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Stress the producer/consumer random-action rollout: fused (split) vs one launch per step, many shapes."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "reinmav-gym_amd"))
+import numpy as np
+import torch
+import gym_reinmav_amd as g
+
+rng = np.random.RandomState(0)
+bad = 0
+for it in range(int(os.environ.get("ITERS", "300"))):
+    kind = ["quad3d", "quad2d", "quad3d_sl", "quad2d_sl"][it % 4]
+    n = int(rng.choice([1, 63, 64, 65, 127, 1000, 10001, 20001, 65536, 70000]))
+    T = int(rng.choice([8, 9, 11, 12, 31, 64, 96]))
+    seed = int(rng.randint(1 << 30))
+    res = []
+    for fused in (True, False):
+        env = g.BatchedQuadrotor(kind, n, seed=seed, auto_reset=True, track_episodes=True)
+        tr = env.rollout(T, mode="random", layout="soa", fused=fused, want=("actions", "obs", "rew", "done"), device_out=True)
+        res.append((tr, env.get_state(layout="soa", device_out=True), env.episode_totals(), env.episode_buffers(device_out=True)))
+        env.close()
+    (a, sa, ta, ea), (b, sb, tb, eb) = res
+    ok = all(torch.equal(a[k], b[k]) for k in a) and torch.equal(sa, sb) and ta["episodes"] == tb["episodes"] \
+        and ta["length_sum"] == tb["length_sum"] and all(torch.equal(ea[k], eb[k]) for k in ea)
+    if not ok:
+        bad += 1
+        which = [k for k in a if not torch.equal(a[k], b[k])]
+        print("MISMATCH", it, kind, n, T, seed, which, ta, tb, flush=True)
+        for k in which:
+            d = (a[k] != b[k]).nonzero()
+            print("  ", k, "first diffs", d[:5].tolist(), "count", len(d), flush=True)
+print("done, mismatches:", bad)
