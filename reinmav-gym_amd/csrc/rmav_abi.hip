@@ -166,8 +166,9 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
     if constexpr (MODE == ACT_RANDOM_SPLIT) {   // two wavefronts (integrator + action producer) per 64 envs
+        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA>;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + 63) / 64)), dim3(128),
-                           sizeof(float) * SplitTile<Dims<K>::NA>::WORDS, h->stream, a, p, pc);
+                           sizeof(float) * Tile::WORDS, h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     }

@@ -31,9 +31,14 @@ namespace rmav {
 enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4,
               // internal: ACT_RANDOM with the action draws on a second wavefront of the workgroup (see k_rollout)
               ACT_RANDOM_SPLIT = 5 };
-// ACT_RANDOM_SPLIT: env-steps drawn per hand-over, and the LDS words of the double-buffered action tile
-constexpr int kSplitChunk = 4;
-template <int NA> struct SplitTile { static constexpr int HALF = kSplitChunk * NA * 64, WORDS = 2 * HALF; };
+// ACT_RANDOM_SPLIT: env-steps per hand-over, and the LDS words of the two double-buffered tiles
+// (actions: helper -> integrator; obs + reward + done: integrator -> helper)
+constexpr int kSplitChunk = 2;
+template <int NS, int NA> struct SplitTile {
+    static constexpr int A_HALF = kSplitChunk * NA * 64, A_WORDS = 2 * A_HALF;
+    static constexpr int O_ROW = (NS + 2) * 64, O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
+    static constexpr int WORDS = A_WORDS + O_WORDS;
+};
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
 constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
@@ -153,45 +158,93 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
 
-    // ACT_RANDOM_SPLIT.  At C2 (65 536 envs = one wavefront per SIMD) the fused kernel is bound by how fast ONE
-    // wavefront can issue instructions (~5 cycles each, VALU + SALU + branches in one stream: 0.72 us per
-    // env-step without any store, against 0.34 us per wavefront-step when 16 wavefronts share a SIMD), and a
-    // third of that stream is the Philox draw of the next action - work that does not depend on the state.
-    // So the workgroup gets a second wavefront for the same 64 envs: it draws kSplitChunk env-steps of actions
-    // ahead into a double-buffered LDS tile (and writes the action trajectory), the first wavefront integrates.
-    // Two instruction streams per SIMD instead of one; one s_barrier per kSplitChunk env-steps.  Same counters,
-    // same bits as ACT_RANDOM.  Lanes past the end of the batch are clones of env N-1 (as in the MFMA mode) so
-    // that every lane of both wavefronts reaches every barrier.
+    // ACT_RANDOM_SPLIT.  At C2 (65 536 envs = one wavefront per SIMD) the single-wavefront kernel is bound twice
+    // over: ONE wavefront issues its ~340 instructions per env-step (VALU + SALU + branches, one stream) at ~5
+    // cycles each - 0.72 us per env-step with every output switched off, against 0.34 us per wavefront-step when
+    // 16 wavefronts share a SIMD - and then stalls on its own burst of 16 stores, while a store-only kernel
+    // with the same pattern drains the trajectory at 7 TB/s (tools/micro/write_ceiling.hip: 36 us per 64 steps).
+    // So each 64 envs get a second, "memory" wavefront:
+    //   helper  (wave 1): draws the actions (Philox - a third of the instruction stream, independent of the
+    //                     state) kSplitChunk env-steps ahead into an LDS tile, and issues EVERY trajectory
+    //                     store: actions directly, obs / reward / done from a second LDS tile the integrator
+    //                     fills.  It is the only wavefront that ever waits on the memory pipeline.
+    //   integrator (wave 0): state in registers, reads actions from LDS, writes its outputs to LDS.
+    // Both tiles are double-buffered; one s_barrier per kSplitChunk env-steps swaps the halves of both.
+    //   helper:     fill A(0) | B0 | fill A(1)          | B1 | fill A(2), drain O(0) | B2 | ... | B(nc) | drain O(nc-1)
+    //   integrator:            B0 | chunk 0: A(0)->O(0) | B1 | chunk 1: A(1)->O(1)   | B2 | ... | B(nc)
+    // Same Philox counters, same arithmetic: same bits as ACT_RANDOM.  Lanes past the end of the batch are clones
+    // of env N-1 (as in the MFMA mode) so that every lane of both wavefronts reaches every barrier.
     if constexpr (MODE == ACT_RANDOM_SPLIT) {
+        using ST_ = SplitTile<NS, NA>;
         if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1u) {
             const uint64_t env_id = a.env_base + (uint64_t)li;
             const uint32_t lane = threadIdx.x & 63u;
-            float *act_out = a.act_out;
-            for (int32_t k0 = 0; k0 < a.n_steps; k0 += kSplitChunk) {
-                float *buf = lds_w + ((k0 / kSplitChunk) & 1) * SplitTile<NA>::HALF + lane;
+            const int32_t T = a.n_steps;
+            const int32_t nc = (T + kSplitChunk - 1) / kSplitChunk;
+            auto fill = [&](int32_t c) {   // actions of chunk c: draw, hand over, write the action trajectory
+                float *buf = lds_w + (c & 1) * ST_::A_HALF + lane;
 #pragma unroll
                 for (int j = 0; j < kSplitChunk; ++j) {
-                    if (k0 + j < a.n_steps) {
+                    const int32_t k = c * kSplitChunk + j;
+                    if (k < T) {
                         float act[NA];
-                        random_action<K>(a.seed, env_id, a.t0 + (uint64_t)(k0 + j), a.act_lo, a.act_hi, act);
+                        random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
 #pragma unroll
-                        for (int c = 0; c < NA; ++c) buf[(j * NA + c) * 64] = act[c];
-                        if (act_out) {
+                        for (int q = 0; q < NA; ++q) buf[(j * NA + q) * 64] = act[q];
+                        if (a.act_out) {
+                            float *dst_step = a.act_out + (int64_t)k * NA * n;
                             if (aos) {
-                                float *dst = act_out + (int64_t)li * NA;
+                                float *dst = dst_step + (int64_t)li * NA;
 #pragma unroll
-                                for (int c = 0; c < NA; ++c) dst[c] = act[c];
+                                for (int q = 0; q < NA; ++q) dst[q] = act[q];
                             } else {
-                                const rsrc_t ra = make_rsrc(act_out);
+                                const rsrc_t ra = make_rsrc(dst_step);
 #pragma unroll
-                                for (int c = 0; c < NA; ++c) buf_st_aux<AUX>(ra, off, (uint32_t)c * col, act[c]);
+                                for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * col, act[q]);
                             }
-                            act_out += (int64_t)NA * n;
                         }
                     }
                 }
-                __syncthreads();   // hand-over k0 / kSplitChunk
+            };
+            auto drain = [&](int32_t c) {  // obs / reward / done of chunk c: LDS -> trajectory
+                const float *buf = lds_w + ST_::A_WORDS + (c & 1) * ST_::O_HALF + lane;
+#pragma unroll
+                for (int j = 0; j < kSplitChunk; ++j) {
+                    const int32_t k = c * kSplitChunk + j;
+                    if (k < T) {
+                        const float *row = buf + j * ST_::O_ROW;
+                        if (a.obs_out) {
+                            float *dst_step = a.obs_out + (int64_t)k * NS * n;
+                            float o[NS];
+#pragma unroll
+                            for (int q = 0; q < NS; ++q) o[q] = row[q * 64];
+                            if (aos) {
+                                float *dst = dst_step + (int64_t)li * NS;
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) dst[q] = o[q];
+                            } else {
+                                const rsrc_t ro = make_rsrc(dst_step);
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, off, (uint32_t)q * col, o[q]);
+                            }
+                        }
+                        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k * n), off, 0, row[NS * 64]);
+                        if (a.done_out)
+                            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row[(NS + 1) * 64] != 0.0f ? 1 : 0),
+                                                                 make_rsrc(a.done_out + (int64_t)k * n), li, 0, 0);
+                    }
+                }
+            };
+            fill(0);
+            __syncthreads();                                   // B0
+            for (int32_t c = 1; c < nc; ++c) {
+                fill(c);
+                if (c >= 2) drain(c - 2);
+                __syncthreads();                               // Bc
             }
+            if (nc >= 2) drain(nc - 2);
+            __syncthreads();                                   // B(nc)
+            drain(nc - 1);
             return;
         }
     }
@@ -365,8 +418,8 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
-                if ((k % kSplitChunk) == 0) __syncthreads();   // the producer has filled tile half (k / chunk) & 1
-                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NA>::HALF +
+                if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
+                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NS, NA>::A_HALF +
                                    (k % kSplitChunk) * (NA * 64) + (threadIdx.x & 63u);
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
@@ -439,7 +492,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
                 rc += 1;
             }
-            if (obs_out) {
+            if constexpr (MODE == ACT_RANDOM_SPLIT) {
+                // hand obs / reward / done to the memory wavefront (it drains this half two barriers later)
+                float *row = lds_w + SplitTile<NS, NA>::A_WORDS + ((k / kSplitChunk) & 1) * SplitTile<NS, NA>::O_HALF +
+                             (k % kSplitChunk) * SplitTile<NS, NA>::O_ROW + (threadIdx.x & 63u);
+                if (obs_out) {
+#pragma unroll
+                    for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
+                }
+                row[NS * 64] = r;
+                row[(NS + 1) * 64] = done ? 1.0f : 0.0f;
+            } else if (obs_out) {
                 if (ST == ST_AOS_LDS && full_wave) {
                     // all 64 lanes are here (full_wave is wave-uniform); LDS executes one wavefront's
                     // instructions in order, the fences only pin the compiler's ordering
@@ -466,15 +529,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
                 obs_out += (int64_t)NS * n;
             }
-            if (rew_out) {
+            if (MODE != ACT_RANDOM_SPLIT && rew_out) {
                 buf_st_aux<AUX>(make_rsrc(rew_out), off, 0, r);
                 rew_out += n;
             }
-            if (done_out) {
+            if (MODE != ACT_RANDOM_SPLIT && done_out) {
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(done_out), li, 0, 0);
                 done_out += n;
             }
         }
+        if constexpr (MODE == ACT_RANDOM_SPLIT) __syncthreads();   // B(nc): the last chunk's outputs are in LDS
 
         if constexpr (MODE == ACT_POLICY_BF16) {   // bootstrap value of the state the rollout ends in
             float x[16], mean[4], val0;
