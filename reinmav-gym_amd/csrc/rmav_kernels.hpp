@@ -33,7 +33,10 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
               ACT_RANDOM_SPLIT = 5 };
 // ACT_RANDOM_SPLIT: env-steps per hand-over, and the LDS words of the two double-buffered tiles
 // (actions: helper -> integrator; obs + reward + done: integrator -> helper)
-constexpr int kSplitChunk = 2;
+#ifndef RMAV_SPLIT_CHUNK
+#define RMAV_SPLIT_CHUNK 2
+#endif
+constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 template <int NS, int NA> struct SplitTile {
     static constexpr int A_HALF = kSplitChunk * NA * 64, A_WORDS = 2 * A_HALF;
     static constexpr int O_ROW = (NS + 2) * 64, O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;

@@ -41,8 +41,30 @@ template <> struct Dims<REINMAV>   { static constexpr int NS = 13, NA = 4; using
 // ---- scalar helpers -----------------------------------------------------------------------------
 RMAV_HD float  rfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 RMAV_HD double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-RMAV_HD float  rsqrt_ieee(float x)  { return __builtin_sqrtf(x); }
-RMAV_HD double rsqrt_ieee(double x) { return __builtin_sqrt(x); }
+// Square roots.  fp64 (slung-load kinds, controllers, reinmav): the correctly rounded one.  fp32 (quad2d / quad3d):
+// on the device the hardware's 1-ulp v_sqrt_f32 / v_rsq_f32.  hipcc's IEEE-exact sqrtf and 1/x are 12-14
+// dependent instructions each (scale, v_sqrt/v_rcp, two fma refinements, fix-ups), the fp32 step has three of
+// them on its critical path, and at one wavefront per SIMD that chain - not the issue rate - sets the step
+// time.  1 ulp = 6e-8 relative, an order of magnitude inside the 1e-6 parity bar (measured worst error of the
+// whole step vs the fp64 oracle stays < 3e-7).  The host test build keeps the correctly rounded versions, so host
+// and device may differ in the last bit of a norm; the parity tests compare both with the oracle, not with
+// each other.  The hardware instructions flush denormal inputs, hence the FLT_MIN guards.
+RMAV_HD float  root(float x)  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+RMAV_HD double root(double x) { return __builtin_sqrt(x); }
+// 1/sqrt(x) for x > 0
+RMAV_HD float inv_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (x >= 1.17549435e-38f) return __builtin_amdgcn_rsqf(x);
+#endif
+    return 1.0f / __builtin_sqrtf(x);
+}
+RMAV_HD double inv_sqrt(double x) { return 1.0 / __builtin_sqrt(x); }
 RMAV_HD float  rabs(float x)  { return __builtin_fabsf(x); }
 RMAV_HD double rabs(double x) { return __builtin_fabs(x); }
 
@@ -132,8 +154,7 @@ template <typename R> RMAV_HD void quat_normalise(const R (&q)[4], R (&o)[4]) {
     const R n2 = rfma(q[0], q[0], rfma(q[1], q[1], rfma(q[2], q[2], q[3] * q[3])));
     R s = R(1);
     if (!(rabs(R(1) - n2) < R(1e-14))) {
-        const R n = rsqrt_ieee(n2);
-        if (n > R(0)) s = R(1) / n;
+        if (n2 > R(0)) s = inv_sqrt(n2);   // n2 == 0 (or NaN): left alone, like _normalise
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = q[i] * s;
@@ -191,8 +212,8 @@ template <> struct Env<QUAD3D> {
         quat_integrate(q, qn, w, p.dt, qo);          // :101-102
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[3 + i] = qo[i];
-        const R np = rsqrt_ieee(rfma(s[0], s[0], rfma(s[1], s[1], s[2] * s[2])));
-        const R nv = rsqrt_ieee(rfma(s[7], s[7], rfma(s[8], s[8], s[9] * s[9])));
+        const R np = root(rfma(s[0], s[0], rfma(s[1], s[1], s[2] * s[2])));
+        const R nv = root(rfma(s[7], s[7], rfma(s[8], s[8], s[9] * s[9])));
         done = (np > p.pos_limit) || (nv > p.vel_limit);   // :106-110 (the "< -thr" clauses are dead)
         dist = np;                                   // :113 reward = -|pos|
     }
@@ -215,7 +236,7 @@ template <> struct Env<QUAD3D_SL> {
         quat_normalise(q, qn);
         quat_body_z(qn, b);
         const R tv[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};     // :101
-        const R d = rsqrt_ieee(rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2])));
+        const R d = root(rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2])));
         const bool taut = d >= p.L;                                           // :104
         const R k = thrust * p.inv_mass;
         R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};                 // :118 / :140
@@ -233,7 +254,7 @@ template <> struct Env<QUAD3D_SL> {
             la[2] = rfma(f, u[2], -p.g);
             // :115 T = m_l * |a_l - g| * u ;  a_l - g = f*u  (exactly, before rounding)
             const R ag[3] = {la[0], la[1], la[2] + p.g};
-            const R tn = p.load_mass * rsqrt_ieee(rfma(ag[0], ag[0], rfma(ag[1], ag[1], ag[2] * ag[2])));
+            const R tn = p.load_mass * root(rfma(ag[0], ag[0], rfma(ag[1], ag[1], ag[2] * ag[2])));
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);   // :118 + T/mass
         }
@@ -247,7 +268,7 @@ template <> struct Env<QUAD3D_SL> {
         quat_integrate(q, qn, w, p.dt, qo);                                   // :122-123 / :144-145
         if (taut) {                                                           // :126-128 projection
             const R e[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};
-            const R inv_n = R(1) / rsqrt_ieee(rfma(e[0], e[0], rfma(e[1], e[1], e[2] * e[2])));
+            const R inv_n = R(1) / root(rfma(e[0], e[0], rfma(e[1], e[1], e[2] * e[2])));
             const R dir[3] = {e[0] * inv_n, e[1] * inv_n, e[2] * inv_n};
             const R pr = rfma(lv[0] - vel[0], dir[0],
                               rfma(lv[1] - vel[1], dir[1], (lv[2] - vel[2]) * dir[2]));
@@ -266,8 +287,8 @@ template <> struct Env<QUAD3D_SL> {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[3 + i] = (float)qo[i];
-        const R nlp = rsqrt_ieee(rfma(lp[0], lp[0], rfma(lp[1], lp[1], lp[2] * lp[2])));
-        const R nv = rsqrt_ieee(rfma(vel[0], vel[0], rfma(vel[1], vel[1], vel[2] * vel[2])));
+        const R nlp = root(rfma(lp[0], lp[0], rfma(lp[1], lp[1], lp[2] * lp[2])));
+        const R nv = root(rfma(vel[0], vel[0], rfma(vel[1], vel[1], vel[2] * vel[2])));
         done = (nlp > p.pos_limit) || (nv > p.vel_limit);   // :149-153 load position, quad velocity
         dist = (float)nlp;                                  // :156 reward = -|load_pos|
     }
@@ -293,8 +314,8 @@ template <> struct Env<QUAD2D> {
             s[3 + i] = rfma(acc[i], p.dt, v);                      // :90
         }
         s[2] = rfma(a[1], p.dt, s[2]);                            // :91 (no wrap)
-        const R np = rsqrt_ieee(rfma(s[0], s[0], s[1] * s[1]));
-        const R nv = rsqrt_ieee(rfma(s[3], s[3], s[4] * s[4]));
+        const R np = root(rfma(s[0], s[0], s[1] * s[1]));
+        const R nv = root(rfma(s[3], s[3], s[4] * s[4]));
         done = (np > p.pos_limit) || (nv > p.vel_limit);          // :95-98 under the chosen reading
         dist = np;                                                // :102
     }
@@ -316,7 +337,7 @@ template <> struct Env<QUAD2D_SL> {
         sincosf(s[2], &sn, &cs);
         const R dir[2] = {-(R)sn, (R)cs};
         const R tv[2] = {lp[0] - pos[0], lp[1] - pos[1]};         // :92
-        const R d = rsqrt_ieee(rfma(tv[0], tv[0], tv[1] * tv[1]));
+        const R d = root(rfma(tv[0], tv[0], tv[1] * tv[1]));
         const bool taut = d >= p.L;                               // :95
         const R k = thrust * p.inv_mass;
         R acc[2] = {k * dir[0], rfma(k, dir[1], -p.g)};           // :107 / :128
@@ -330,7 +351,7 @@ template <> struct Env<QUAD2D_SL> {
             la[0] = f * u[0];
             la[1] = rfma(f, u[1], -p.g);
             const R ag[2] = {la[0], la[1] + p.g};
-            const R tn = p.load_mass * rsqrt_ieee(rfma(ag[0], ag[0], ag[1] * ag[1]));   // :102
+            const R tn = p.load_mass * root(rfma(ag[0], ag[0], ag[1] * ag[1]));   // :102
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);
         }
@@ -344,7 +365,7 @@ template <> struct Env<QUAD2D_SL> {
         const float th = rfma(a[1], (float)p.dt, s[2]);                        // :110 / :131
         if (taut) {                                                            // :113-115
             const R e[2] = {lp[0] - pos[0], lp[1] - pos[1]};
-            const R inv_n = R(1) / rsqrt_ieee(rfma(e[0], e[0], e[1] * e[1]));
+            const R inv_n = R(1) / root(rfma(e[0], e[0], e[1] * e[1]));
             const R dr[2] = {e[0] * inv_n, e[1] * inv_n};
             const R pr = rfma(lv[0] - vel[0], dr[0], (lv[1] - vel[1]) * dr[1]);
 #pragma unroll
@@ -357,10 +378,10 @@ template <> struct Env<QUAD2D_SL> {
         s[3] = (float)vel[0]; s[4] = (float)vel[1];
         s[5] = (float)lp[0];  s[6] = (float)lp[1];
         s[7] = (float)lv[0];  s[8] = (float)lv[1];
-        const R nlp = rsqrt_ieee(rfma(lp[0], lp[0], lp[1] * lp[1]));
-        const R nlv = rsqrt_ieee(rfma(lv[0], lv[0], lv[1] * lv[1]));
+        const R nlp = root(rfma(lp[0], lp[0], lp[1] * lp[1]));
+        const R nlv = root(rfma(lv[0], lv[0], lv[1] * lv[1]));
         done = (nlp > p.pos_limit) || (nlv > p.vel_limit);        // :136-140 load pos, load vel
-        dist = (float)rsqrt_ieee(rfma(pos[0], pos[0], pos[1] * pos[1]));   // :143 reward = -|quad pos|
+        dist = (float)root(rfma(pos[0], pos[0], pos[1] * pos[1]));   // :143 reward = -|quad pos|
     }
 };
 
@@ -376,15 +397,15 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
         ad[i] = rfma(p.kp, (R)s[i] - p.ref_pos[i], p.kv * ((R)s[7 + i] - p.ref_vel[i]));
     ad[2] += p.g;                                                 // - g, g = (0,0,-9.8)
     // acc2quat :127-141 ; yc = (0,1,0)
-    const R inv_n = R(1) / rsqrt_ieee(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
+    const R inv_n = R(1) / root(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
     R zb[3] = {ad[0] * inv_n, ad[1] * inv_n, ad[2] * inv_n};
     R xb[3] = {zb[2], R(0), -zb[0]};                              // cross(yc, zb)
-    const R inv_x = R(1) / rsqrt_ieee(rfma(xb[0], xb[0], xb[2] * xb[2]));
+    const R inv_x = R(1) / root(rfma(xb[0], xb[0], xb[2] * xb[2]));
     xb[0] *= inv_x;
     xb[2] *= inv_x;
     const R yb[3] = {rfma(zb[1], xb[2], -(zb[2] * xb[1])), rfma(zb[2], xb[0], -(zb[0] * xb[2])),
                      rfma(zb[0], xb[1], -(zb[1] * xb[0]))};       // cross(zb, xb)
-    const R inv_z = R(1) / rsqrt_ieee(rfma(zb[0], zb[0], rfma(zb[1], zb[1], zb[2] * zb[2])));
+    const R inv_z = R(1) / root(rfma(zb[0], zb[0], rfma(zb[1], zb[1], zb[2] * zb[2])));
 #pragma unroll
     for (int i = 0; i < 3; ++i) zb[i] *= inv_z;
     // Quaternion(matrix=[xb yb zb]) : trace method on m = R^T  (m[i][j] = R[j][i])
@@ -410,7 +431,7 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
             qd[0] = t; qd[1] = m12 - m21; qd[2] = m20 - m02; qd[3] = m01 - m10;
         }
     }
-    const R kq = R(0.5) / rsqrt_ieee(t);
+    const R kq = R(0.5) / root(t);
 #pragma unroll
     for (int i = 0; i < 4; ++i) qd[i] *= kq;
     // error_att = conj(q_raw) (x) q_des   :169   (the stored quaternion is NOT normalised here)
@@ -440,7 +461,7 @@ RMAV_HD void control_2d(const float (&s)[NS], const ParamsT<double> &p, float (&
     const R ay = rfma(p.kp, (R)s[1] - p.ref_pos[1], p.kv * ((R)s[4] - p.ref_vel[1])) + p.g;  // :130
     const R th_d = atan2(ay, ax) - R(1.5707963267948966);         // :131
     a[1] = (float)(p.neg_inv_tau * ((R)s[2] - th_d));             // :132-133
-    a[0] = (float)(p.mass * rsqrt_ieee(rfma(ax, ax, ay * ay)));   // :134
+    a[0] = (float)(p.mass * root(rfma(ax, ax, ay * ay)));   // :134
 }
 
 // ================================================================================================
