@@ -41,14 +41,14 @@ template <> struct Dims<REINMAV>   { static constexpr int NS = 13, NA = 4; using
 // ---- scalar helpers -----------------------------------------------------------------------------
 RMAV_HD float  rfma(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
 RMAV_HD double rfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// Square roots.  fp64 (slung-load kinds, controllers, reinmav): the correctly rounded one.  fp32 (quad2d / quad3d):
-// on the device the hardware's 1-ulp v_sqrt_f32 / v_rsq_f32.  hipcc's IEEE-exact sqrtf and 1/x are 12-14
+// Square roots and reciprocal square roots.  The host test build uses the correctly rounded libm forms.
+// fp32 (quad2d / quad3d) on the device: the hardware's 1-ulp v_sqrt_f32 / v_rsq_f32.  hipcc's IEEE-exact sqrtf and 1/x are 12-14
 // dependent instructions each (scale, v_sqrt/v_rcp, two fma refinements, fix-ups), the fp32 step has three of
 // them on its critical path, and at one wavefront per SIMD that chain - not the issue rate - sets the step
 // time.  1 ulp = 6e-8 relative, an order of magnitude inside the 1e-6 parity bar (measured worst error of the
 // whole step vs the fp64 oracle stays < 3e-7).  The host test build keeps the correctly rounded versions, so host
 // and device may differ in the last bit of a norm; the parity tests compare both with the oracle, not with
-// each other.  The hardware instructions flush denormal inputs, hence the FLT_MIN guards.
+// each other.  The hardware instructions flush denormal inputs, hence the FLT_MIN guard.
 RMAV_HD float  root(float x)  {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_sqrtf(x);
@@ -56,15 +56,36 @@ RMAV_HD float  root(float x)  {
     return __builtin_sqrtf(x);
 #endif
 }
-RMAV_HD double root(double x) { return __builtin_sqrt(x); }
-// 1/sqrt(x) for x > 0
-RMAV_HD float inv_sqrt(float x) {
+RMAV_HD float inv_sqrt(float x) {   // 1/sqrt(x)
 #if defined(__HIP_DEVICE_COMPILE__)
     if (x >= 1.17549435e-38f) return __builtin_amdgcn_rsqf(x);
 #endif
     return 1.0f / __builtin_sqrtf(x);
 }
-RMAV_HD double inv_sqrt(double x) { return 1.0 / __builtin_sqrt(x); }
+// fp64 on the device: v_rsq_f64 is a ~single-precision estimate; hipcc's correctly rounded sqrt / divide
+// wrap it in 15-25 more fp64 instructions (half rate).  One Newton step takes the estimate to <= 1e-12
+// relative, and every fp64 result of these kinds is rounded to fp32 storage (6e-8) at the end of the step, so
+// the extra digits of the exact sequences are never seen.  Branch-free: for 0, inf, NaN and negative x the
+// raw estimate already is what 1/sqrt(x) returns (inf, 0, NaN, NaN) and is passed through.
+RMAV_HD double inv_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y), 0.5 * y, 0.5);
+    const double r = __builtin_fma(y, e, y);
+    return (x > 0.0 && x < __builtin_inf()) ? r : y;
+#else
+    return 1.0 / __builtin_sqrt(x);
+#endif
+}
+RMAV_HD double root(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = inv_sqrt(x), g = x * y;
+    const double r = __builtin_fma(__builtin_fma(-g, g, x), 0.5 * y, g);   // one correction: g + (x - g^2) * y/2
+    return (x > 0.0 && x < __builtin_inf()) ? r : (x == 0.0 ? x : (x > 0.0 ? x : y));   // 0 -> 0, inf -> inf, else NaN
+#else
+    return __builtin_sqrt(x);
+#endif
+}
 RMAV_HD float  rabs(float x)  { return __builtin_fabsf(x); }
 RMAV_HD double rabs(double x) { return __builtin_fabs(x); }
 
@@ -236,13 +257,14 @@ template <> struct Env<QUAD3D_SL> {
         quat_normalise(q, qn);
         quat_body_z(qn, b);
         const R tv[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};     // :101
-        const R d = root(rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2])));
+        const R dd = rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2]));
+        const R d = root(dd);
         const bool taut = d >= p.L;                                           // :104
         const R k = thrust * p.inv_mass;
         R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};                 // :118 / :140
         R la[3] = {R(0), R(0), -p.g};                                         // :134 slack: a_l = g
         if (taut) {
-            const R inv_d = R(1) / d;
+            const R inv_d = inv_sqrt(dd);
             const R u[3] = {tv[0] * inv_d, tv[1] * inv_d, tv[2] * inv_d};     // :102
             const R c = p.mL * rfma(lv[0], lv[0], rfma(lv[1], lv[1], lv[2] * lv[2]));
             // :110 inner(u, thrust_vec - c) with the scalar c broadcast over the vector
@@ -268,7 +290,7 @@ template <> struct Env<QUAD3D_SL> {
         quat_integrate(q, qn, w, p.dt, qo);                                   // :122-123 / :144-145
         if (taut) {                                                           // :126-128 projection
             const R e[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};
-            const R inv_n = R(1) / root(rfma(e[0], e[0], rfma(e[1], e[1], e[2] * e[2])));
+            const R inv_n = inv_sqrt(rfma(e[0], e[0], rfma(e[1], e[1], e[2] * e[2])));
             const R dir[3] = {e[0] * inv_n, e[1] * inv_n, e[2] * inv_n};
             const R pr = rfma(lv[0] - vel[0], dir[0],
                               rfma(lv[1] - vel[1], dir[1], (lv[2] - vel[2]) * dir[2]));
@@ -337,13 +359,14 @@ template <> struct Env<QUAD2D_SL> {
         sincosf(s[2], &sn, &cs);
         const R dir[2] = {-(R)sn, (R)cs};
         const R tv[2] = {lp[0] - pos[0], lp[1] - pos[1]};         // :92
-        const R d = root(rfma(tv[0], tv[0], tv[1] * tv[1]));
+        const R dd = rfma(tv[0], tv[0], tv[1] * tv[1]);
+        const R d = root(dd);
         const bool taut = d >= p.L;                               // :95
         const R k = thrust * p.inv_mass;
         R acc[2] = {k * dir[0], rfma(k, dir[1], -p.g)};           // :107 / :128
         R la[2] = {R(0), -p.g};                                   // :123
         if (taut) {
-            const R inv_d = R(1) / d;
+            const R inv_d = inv_sqrt(dd);
             const R u[2] = {tv[0] * inv_d, tv[1] * inv_d};        // :93
             const R c = p.mL * rfma(lv[0], lv[0], lv[1] * lv[1]);
             const R sc = rfma(u[0], rfma(thrust, dir[0], -c), u[1] * rfma(thrust, dir[1], -c));  // :97
@@ -365,7 +388,7 @@ template <> struct Env<QUAD2D_SL> {
         const float th = rfma(a[1], (float)p.dt, s[2]);                        // :110 / :131
         if (taut) {                                                            // :113-115
             const R e[2] = {lp[0] - pos[0], lp[1] - pos[1]};
-            const R inv_n = R(1) / root(rfma(e[0], e[0], e[1] * e[1]));
+            const R inv_n = inv_sqrt(rfma(e[0], e[0], e[1] * e[1]));
             const R dr[2] = {e[0] * inv_n, e[1] * inv_n};
             const R pr = rfma(lv[0] - vel[0], dr[0], (lv[1] - vel[1]) * dr[1]);
 #pragma unroll
@@ -397,15 +420,15 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
         ad[i] = rfma(p.kp, (R)s[i] - p.ref_pos[i], p.kv * ((R)s[7 + i] - p.ref_vel[i]));
     ad[2] += p.g;                                                 // - g, g = (0,0,-9.8)
     // acc2quat :127-141 ; yc = (0,1,0)
-    const R inv_n = R(1) / root(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
+    const R inv_n = inv_sqrt(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
     R zb[3] = {ad[0] * inv_n, ad[1] * inv_n, ad[2] * inv_n};
     R xb[3] = {zb[2], R(0), -zb[0]};                              // cross(yc, zb)
-    const R inv_x = R(1) / root(rfma(xb[0], xb[0], xb[2] * xb[2]));
+    const R inv_x = inv_sqrt(rfma(xb[0], xb[0], xb[2] * xb[2]));
     xb[0] *= inv_x;
     xb[2] *= inv_x;
     const R yb[3] = {rfma(zb[1], xb[2], -(zb[2] * xb[1])), rfma(zb[2], xb[0], -(zb[0] * xb[2])),
                      rfma(zb[0], xb[1], -(zb[1] * xb[0]))};       // cross(zb, xb)
-    const R inv_z = R(1) / root(rfma(zb[0], zb[0], rfma(zb[1], zb[1], zb[2] * zb[2])));
+    const R inv_z = inv_sqrt(rfma(zb[0], zb[0], rfma(zb[1], zb[1], zb[2] * zb[2])));
 #pragma unroll
     for (int i = 0; i < 3; ++i) zb[i] *= inv_z;
     // Quaternion(matrix=[xb yb zb]) : trace method on m = R^T  (m[i][j] = R[j][i])
@@ -431,7 +454,7 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
             qd[0] = t; qd[1] = m12 - m21; qd[2] = m20 - m02; qd[3] = m01 - m10;
         }
     }
-    const R kq = R(0.5) / root(t);
+    const R kq = R(0.5) * inv_sqrt(t);
 #pragma unroll
     for (int i = 0; i < 4; ++i) qd[i] *= kq;
     // error_att = conj(q_raw) (x) q_des   :169   (the stored quaternion is NOT normalised here)
