@@ -185,7 +185,9 @@ bool use_split(rmav_handle h, const RolloutArgs &a, int st) {
     }();
     if (a.n_steps < 8 || st == ST_AOS_LDS) return false;
     if (forced == 0 || forced == 1) return forced == 1;
-    return h->n <= kSplitMaxEnvs;
+    // measured (profiles/r01/split_ab.md): fp32 kinds gain up to 131 072 envs, the fp64 slung-load kinds up to 65 536
+    const bool fp32_kind = h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD3D;
+    return h->n <= (fp32_kind ? kSplitMaxEnvs : kSplitMaxEnvs / 2);
 }
 
 template <int K, int MODE>
@@ -195,8 +197,7 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
         return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
     } else {
         const int st = pick_store_policy(h, a);
-        // fp32 kinds only: measured +4..8 % at <= 131 072 envs; the fp64 slung-load kinds gain < 1 % at 65 536 and lose above
-        if constexpr (MODE == ACT_RANDOM && (K == QUAD2D || K == QUAD3D)) {
+        if constexpr (MODE == ACT_RANDOM && K != REINMAV) {
             if (use_split(h, a, st)) {
                 switch (st) {
                 case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_WRITE_THROUGH>(h, a);

@@ -16,11 +16,11 @@ run() {  # name, rocprof args..., -- cmd
   echo "rc=$? $(tail -1 $OUT/$name.log | cut -c1-300)"
 }
 # 1. kernel trace + stats of the exact default bench command (and of the step mode)
-run trace_rollout --kernel-trace --stats --output-format csv -d $OUT/trace_rollout -- $B --steps 100 --warmup 10
+run trace_rollout --kernel-trace --stats --output-format csv -d $OUT/trace_rollout -- $B
 run trace_step    --kernel-trace --stats --output-format csv -d $OUT/trace_step    -- $B --mode step --steps 2000 --warmup 50
 # 2. PMC passes: HBM-side bytes of the dominant kernel (per dispatch)
 for C in FETCH_SIZE WRITE_SIZE; do
-  run pmc_rollout_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_rollout_$C -- $B --steps 20 --warmup 2
+  run pmc_rollout_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_rollout_$C -- $B --steps 40 --warmup 20
   run pmc_step_$C    --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_step_$C    -- $B --mode step --steps 40 --warmup 4
   # calibration: same kernel, working set far beyond the 256 MiB Infinity Cache, known byte count
   run pmc_calib_$C   --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_calib_$C   -- $B --mode step --envs-per-gpu 16777216 --steps 6 --warmup 2

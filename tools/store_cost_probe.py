@@ -11,7 +11,7 @@ kind, n, T = os.environ.get("KIND", "quad3d"), int(os.environ.get("N", "65536"))
 stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
     for want in [(), ("rew", "done"), ("obs",), ("actions",), ("obs", "rew", "done"), ("actions", "obs", "rew", "done")]:
-        env = g.BatchedQuadrotor(kind, n, seed=0)
+        env = g.BatchedQuadrotor(kind, n, seed=0, auto_reset=True, track_episodes=os.environ.get("TRACK", "0") == "1")
         out = env.rollout(T, mode="random", want=want, device_out=True)
         def run():
             env.rollout(T, mode="random", want=want, device_out=True, out=out)
