@@ -103,7 +103,7 @@ int check_params(const rmav_params &q) {
 inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
 
 // Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
-constexpr int64_t kSplitMaxEnvs = 131072;   // measured: see DESIGN.md section 4
+constexpr int64_t kSplitMaxEnvs = 65536;   // measured: see DESIGN.md section 4
 
 int block_size() {
     static int b = [] {
@@ -185,9 +185,10 @@ bool use_split(rmav_handle h, const RolloutArgs &a, int st) {
     }();
     if (a.n_steps < 8 || st == ST_AOS_LDS) return false;
     if (forced == 0 || forced == 1) return forced == 1;
-    // measured (profiles/r01/split_ab.md): fp32 kinds gain up to 131 072 envs, the fp64 slung-load kinds up to 65 536
-    const bool fp32_kind = h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD3D;
-    return h->n <= (fp32_kind ? kSplitMaxEnvs : kSplitMaxEnvs / 2);
+    // measured in steady state (profiles/r01/split_ab.md): +10..21 % at 65 536 envs for every kind; at 131 072 only the
+    // 2-D kinds still gain (+3..9 %), the 3-D ones lose 5..22 %
+    const bool two_d = h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL;
+    return h->n <= (two_d ? 2 * kSplitMaxEnvs : kSplitMaxEnvs);
 }
 
 template <int K, int MODE>

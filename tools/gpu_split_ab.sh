@@ -5,7 +5,8 @@ mkdir -p gpurun_out
 for kind in ${KINDS:-quad3d quad3d_sl quad2d quad2d_sl}; do
   for n in ${NS:-65536 131072 262144 1048576}; do
     for sp in 0 1; do
-      RMAV_SPLIT=$sp timeout 120 python bench.py --kind $kind --envs-per-gpu $n --steps 50 --warmup 5 \
+      S=$(( 65536 * 1500 / n + 100 ))   # >= ~50 ms timed after >= ~10 ms of warm-up
+      RMAV_SPLIT=$sp timeout 120 python bench.py --kind $kind --envs-per-gpu $n --steps $S --warmup $((S / 5)) \
         --cpu-seconds 0 --no-secondary 2>/dev/null | tail -1 | sed "s/^{/{\"split\": $sp, /" >> gpurun_out/split_ab.jsonl
     done
   done
