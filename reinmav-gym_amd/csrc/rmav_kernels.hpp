@@ -39,7 +39,10 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
 constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 template <int NS, int NA> struct SplitTile {
     static constexpr int A_HALF = kSplitChunk * NA * 64, A_WORDS = 2 * A_HALF;
-    static constexpr int O_ROW = (NS + 2) * 64, O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
+    // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
+    // trajectory is batch-major - both conflict-free to write), then reward[64], done[64]
+    static constexpr int OBS_STRIDE = NS | 1, REW = OBS_STRIDE * 64, DONE = REW + 64;
+    static constexpr int O_ROW = DONE + 64, O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
@@ -99,6 +102,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void *p) {
     // raw buffer (stride 0), bounds check disabled (num_records = 2^32-1; lanes are predicated by
     // li < N), word 3 = 0x00020000: the gfx9/CDNA raw-dword format
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, -1, 0x00020000);
+}
+// same, with the hardware range check armed: stores at byte offsets >= `bytes` are dropped (no per-lane predicate)
+__device__ __forceinline__ rsrc_t make_rsrc_bounded(const void *p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
 }
 __device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -184,6 +191,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
             const uint32_t lane = threadIdx.x & 63u;
             const int32_t T = a.n_steps;
             const int32_t nc = (T + kSplitChunk - 1) / kSplitChunk;
+            // batch-major obs: output dword 64 q + lane of this wavefront is component e % NS of its env e / NS
+            const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
+            const uint32_t n_here = (uint64_t)wave_first + 64u <= (uint64_t)n ? 64u : (uint32_t)(n - wave_first);
+            const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
+            uint32_t aos_rd[NS];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                const uint32_t e = 64u * q + lane;
+                aos_rd[q] = (e / NS) * ST_::OBS_STRIDE + (e % NS);
+            }
             auto fill = [&](int32_t c) {   // actions of chunk c: draw, hand over, write the action trajectory
                 float *buf = lds_w + (c & 1) * ST_::A_HALF + lane;
 #pragma unroll
@@ -219,21 +236,27 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                         if (a.obs_out) {
                             float *dst_step = a.obs_out + (int64_t)k * NS * n;
                             float o[NS];
-#pragma unroll
-                            for (int q = 0; q < NS; ++q) o[q] = row[q * 64];
                             if (aos) {
-                                float *dst = dst_step + (int64_t)li * NS;
+                                // batch-major: the integrator wrote [env][c]; read it back in output order, so the
+                                // wavefront's 64 x NS floats leave as NS contiguous 256-byte stores.  The buffer
+                                // descriptor covers exactly this wavefront's valid rows: clones are range-checked away.
+                                const float *tile = row - lane;
+                                const rsrc_t ro = make_rsrc_bounded(dst_step + (int64_t)wave_first * NS, aos_bytes);
 #pragma unroll
-                                for (int q = 0; q < NS; ++q) dst[q] = o[q];
+                                for (int q = 0; q < NS; ++q) o[q] = tile[aos_rd[q]];
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, lane * 4u, 256u * q, o[q]);
                             } else {
                                 const rsrc_t ro = make_rsrc(dst_step);
+#pragma unroll
+                                for (int q = 0; q < NS; ++q) o[q] = row[q * 64];
 #pragma unroll
                                 for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, off, (uint32_t)q * col, o[q]);
                             }
                         }
-                        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k * n), off, 0, row[NS * 64]);
+                        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k * n), off, 0, row[ST_::REW]);
                         if (a.done_out)
-                            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row[(NS + 1) * 64] != 0.0f ? 1 : 0),
+                            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row[ST_::DONE] != 0.0f ? 1 : 0),
                                                                  make_rsrc(a.done_out + (int64_t)k * n), li, 0, 0);
                     }
                 }
@@ -500,11 +523,17 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 float *row = lds_w + SplitTile<NS, NA>::A_WORDS + ((k / kSplitChunk) & 1) * SplitTile<NS, NA>::O_HALF +
                              (k % kSplitChunk) * SplitTile<NS, NA>::O_ROW + (threadIdx.x & 63u);
                 if (obs_out) {
+                    if (aos) {   // env-major for the batch-major drain
+                        float *mine = row + (threadIdx.x & 63u) * (SplitTile<NS, NA>::OBS_STRIDE - 1);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
+                        for (int c = 0; c < NS; ++c) mine[c] = s[c];
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
+                    }
                 }
-                row[NS * 64] = r;
-                row[(NS + 1) * 64] = done ? 1.0f : 0.0f;
+                row[SplitTile<NS, NA>::REW] = r;
+                row[SplitTile<NS, NA>::DONE] = done ? 1.0f : 0.0f;
             } else if (obs_out) {
                 if (ST == ST_AOS_LDS && full_wave) {
                     // all 64 lanes are here (full_wave is wave-uniform); LDS executes one wavefront's

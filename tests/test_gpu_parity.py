@@ -313,14 +313,15 @@ def test_fused_trajectory_larger_than_4_GiB(G):
     ref.close()
 
 
+@pytest.mark.parametrize("n,T", [((1 << 19) + 37, 64), (20037, 24), (63, 9)])
 @pytest.mark.parametrize("kind", KINDS)
-def test_batch_major_trajectory_of_a_big_launch(G, kind):
-    """A launch that writes > 768 MB with layout='aos' takes the LDS-transposed obs stores (full wavefronts)
-    plus the direct path for the ragged last wavefront: its [T][N][nS] trajectory must be the [T][nS][N] one
-    transposed, bit for bit."""
+def test_batch_major_trajectory_of_a_big_launch(G, kind, n, T):
+    """layout='aos' ([T][N][nS]) must be the [T][nS][N] trajectory transposed, bit for bit, on every store path:
+    a launch that writes > 448 MB takes the LDS-transposed obs stores (full wavefronts) plus the direct path for
+    the ragged last wavefront; small batches run the two-wavefront kernel, whose memory wavefront drains the
+    hand-over tile in output order (ragged last wavefront masked)."""
     import torch
 
-    n, T = (1 << 19) + 37, 64
     out = {}
     for layout in ("soa", "aos"):
         env = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)

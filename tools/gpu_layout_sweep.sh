@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for kind in quad3d quad3d_sl; do
   for n in 65536 262144 1048576; do
     for layout in soa aos; do
-      timeout 120 python bench.py --kind $kind --envs-per-gpu $n --layout $layout --steps 50 --warmup 5 \
+      timeout 120 python bench.py --kind $kind --envs-per-gpu $n --layout $layout --steps $(( 65536 * 1500 / n + 100 )) --warmup $(( 65536 * 300 / n + 20 )) \
         --cpu-seconds 0 --no-secondary 2>/dev/null | tail -1 >> gpurun_out/layout_sweep.jsonl
     done
   done

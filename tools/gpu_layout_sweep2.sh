@@ -7,7 +7,7 @@ for kind in quad3d quad3d_sl; do
     for cfg in "soa -1" "aos 0" "aos 3"; do
       set -- $cfg
       if [ "$2" = "-1" ]; then unset RMAV_STORE_POLICY; else export RMAV_STORE_POLICY=$2; fi
-      timeout 120 python bench.py --kind $kind --envs-per-gpu $n --layout $1 --steps 50 --warmup 5 \
+      timeout 120 python bench.py --kind $kind --envs-per-gpu $n --layout $1 --steps $(( 65536 * 1500 / n + 100 )) --warmup $(( 65536 * 300 / n + 20 )) \
         --cpu-seconds 0 --no-secondary 2>/dev/null | tail -1 | sed "s/^{/{\"policy\": \"$2\", /" >> gpurun_out/layout_sweep2.jsonl
     done
   done
