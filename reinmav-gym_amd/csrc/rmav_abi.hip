@@ -165,8 +165,8 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
-    if constexpr (MODE == ACT_RANDOM_SPLIT) {   // two wavefronts (integrator + action producer) per 64 envs
-        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA>;
+    if constexpr (is_split(MODE)) {   // two wavefronts (integrator + memory wavefront) per 64 envs
+        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, MODE == ACT_RANDOM_SPLIT>;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + 63) / 64)), dim3(128),
                            sizeof(float) * Tile::WORDS, h->stream, a, p, pc);
     } else {
@@ -178,7 +178,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
 
 // Random-action rollouts of small batches run with the action draws on a second wavefront (ACT_RANDOM_SPLIT in
 // rmav_kernels.hpp): it pays while the batch leaves SIMDs under-occupied.  RMAV_SPLIT=0|1 overrides.
-bool use_split(rmav_handle h, const RolloutArgs &a, int st) {
+bool use_split(rmav_handle h, const RolloutArgs &a, int st, bool draws = true) {
     static const int forced = [] {
         const char *e = getenv("RMAV_SPLIT");
         return e ? atoi(e) : -1;
@@ -187,8 +187,9 @@ bool use_split(rmav_handle h, const RolloutArgs &a, int st) {
     if (forced == 0 || forced == 1) return forced == 1;
     // measured in steady state (profiles/r01/split_ab.md): +10..21 % at 65 536 envs for every kind; at 131 072 only the
     // 2-D kinds still gain (+3..9 %), the 3-D ones lose 5..22 %
+    // controller-driven rollouts (the helper only drains): +14..28 % at 65 536 envs, a loss at 131 072 for every kind
     const bool two_d = h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL;
-    return h->n <= (two_d ? 2 * kSplitMaxEnvs : kSplitMaxEnvs);
+    return h->n <= ((two_d && draws) ? 2 * kSplitMaxEnvs : kSplitMaxEnvs);
 }
 
 template <int K, int MODE>
@@ -204,6 +205,15 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
                 case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_WRITE_THROUGH>(h, a);
                 case ST_STREAM: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_STREAM>(h, a);
                 default: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_DEFAULT>(h, a);
+                }
+            }
+        }
+        if constexpr (MODE == ACT_CONTROLLER && K != REINMAV) {
+            if (use_split(h, a, st, false)) {
+                switch (st) {
+                case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_WRITE_THROUGH>(h, a);
+                case ST_STREAM: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_STREAM>(h, a);
+                default: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_DEFAULT>(h, a);
                 }
             }
         }

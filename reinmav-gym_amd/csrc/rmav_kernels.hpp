@@ -29,20 +29,22 @@
 namespace rmav {
 
 enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4,
-              // internal: ACT_RANDOM with the action draws on a second wavefront of the workgroup (see k_rollout)
-              ACT_RANDOM_SPLIT = 5 };
-// ACT_RANDOM_SPLIT: env-steps per hand-over, and the LDS words of the two double-buffered tiles
-// (actions: helper -> integrator; obs + reward + done: integrator -> helper)
+              // internal: ACT_RANDOM / ACT_CONTROLLER with a second, "memory" wavefront per 64 envs (see k_rollout)
+              ACT_RANDOM_SPLIT = 5, ACT_CONTROLLER_SPLIT = 6 };
+constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT; }
+// Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
+// (actions: helper -> integrator, only when the helper draws them; obs + reward + done [+ actions]: integrator -> helper)
 #ifndef RMAV_SPLIT_CHUNK
 #define RMAV_SPLIT_CHUNK 2
 #endif
 constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
-template <int NS, int NA> struct SplitTile {
-    static constexpr int A_HALF = kSplitChunk * NA * 64, A_WORDS = 2 * A_HALF;
+template <int NS, int NA, bool DRAWS = true> struct SplitTile {
+    static constexpr int A_HALF = DRAWS ? kSplitChunk * NA * 64 : 0, A_WORDS = 2 * A_HALF;
     // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
     // trajectory is batch-major - both conflict-free to write), then reward[64], done[64]
     static constexpr int OBS_STRIDE = NS | 1, REW = OBS_STRIDE * 64, DONE = REW + 64;
-    static constexpr int O_ROW = DONE + 64, O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
+    static constexpr int ACT = DONE + 64;   // actions [c][lane], only when the integrator computes them
+    static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
@@ -151,14 +153,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;
     // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
-    const uint32_t gi = (MODE == ACT_RANDOM_SPLIT) ? blockIdx.x * 64u + (threadIdx.x & 63u)
+    constexpr bool SPLIT = is_split(MODE), DRAWS = (MODE == ACT_RANDOM_SPLIT);
+    const uint32_t gi = SPLIT ? blockIdx.x * 64u + (threadIdx.x & 63u)
                                                    : blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
     // exactly what that env's lane does; only the episode totals must not count them.
     const bool valid = gi < (uint64_t)n;
-    const uint32_t li = ((MODE == ACT_POLICY_BF16 || MODE == ACT_RANDOM_SPLIT) && !valid) ? (uint32_t)n - 1u : gi;   // local env index
+    const uint32_t li = ((MODE == ACT_POLICY_BF16 || SPLIT) && !valid) ? (uint32_t)n - 1u : gi;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
@@ -184,8 +187,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     //   integrator:            B0 | chunk 0: A(0)->O(0) | B1 | chunk 1: A(1)->O(1)   | B2 | ... | B(nc)
     // Same Philox counters, same arithmetic: same bits as ACT_RANDOM.  Lanes past the end of the batch are clones
     // of env N-1 (as in the MFMA mode) so that every lane of both wavefronts reaches every barrier.
-    if constexpr (MODE == ACT_RANDOM_SPLIT) {
-        using ST_ = SplitTile<NS, NA>;
+    // ACT_CONTROLLER_SPLIT is the same arrangement without the draws: the integrator evaluates the controller and
+    // hands the action over with its other outputs; the helper only drains.
+    if constexpr (SPLIT) {
+        using ST_ = SplitTile<NS, NA, DRAWS>;
         if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1u) {
             const uint64_t env_id = a.env_base + (uint64_t)li;
             const uint32_t lane = threadIdx.x & 63u;
@@ -233,6 +238,23 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                     const int32_t k = c * kSplitChunk + j;
                     if (k < T) {
                         const float *row = buf + j * ST_::O_ROW;
+                        if constexpr (!DRAWS) {
+                            if (a.act_out) {
+                                float *dst_step = a.act_out + (int64_t)k * NA * n;
+                                float av[NA];
+#pragma unroll
+                                for (int q = 0; q < NA; ++q) av[q] = row[ST_::ACT + q * 64];
+                                if (aos) {
+                                    float *dst = dst_step + (int64_t)li * NA;
+#pragma unroll
+                                    for (int q = 0; q < NA; ++q) dst[q] = av[q];
+                                } else {
+                                    const rsrc_t ra = make_rsrc(dst_step);
+#pragma unroll
+                                    for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * col, av[q]);
+                                }
+                            }
+                        }
                         if (a.obs_out) {
                             float *dst_step = a.obs_out + (int64_t)k * NS * n;
                             float o[NS];
@@ -261,10 +283,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                     }
                 }
             };
-            fill(0);
+            if constexpr (DRAWS) fill(0);
             __syncthreads();                                   // B0
             for (int32_t c = 1; c < nc; ++c) {
-                fill(c);
+                if constexpr (DRAWS) fill(c);
                 if (c >= 2) drain(c - 2);
                 __syncthreads();                               // Bc
             }
@@ -359,7 +381,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 
         // uniform cursors into the time-major trajectory buffers, advanced once per step
         const float *act_in = a.act_in;
-        float *act_out = (MODE != ACT_BUFFER && MODE != ACT_RANDOM_SPLIT) ? a.act_out : nullptr;   // SPLIT: the producer writes them
+        float *act_out = (MODE != ACT_BUFFER && !SPLIT) ? a.act_out : nullptr;   // SPLIT: the memory wavefront writes them
         float *obs_out = a.obs_out;
         float *rew_out = a.rew_out;
         uint8_t *done_out = a.done_out;
@@ -445,10 +467,13 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
                 if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
-                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NS, NA>::A_HALF +
+                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NS, NA, true>::A_HALF +
                                    (k % kSplitChunk) * (NA * 64) + (threadIdx.x & 63u);
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
+            } else if constexpr (MODE == ACT_CONTROLLER_SPLIT) {
+                if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): the output tile swaps halves
+                env_control<K>(s, pc, act);
             } else if constexpr (K == REINMAV) {
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = 0.0f;   // the built-in controller runs inside every sub-step
@@ -518,13 +543,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
                 rc += 1;
             }
-            if constexpr (MODE == ACT_RANDOM_SPLIT) {
-                // hand obs / reward / done to the memory wavefront (it drains this half two barriers later)
-                float *row = lds_w + SplitTile<NS, NA>::A_WORDS + ((k / kSplitChunk) & 1) * SplitTile<NS, NA>::O_HALF +
-                             (k % kSplitChunk) * SplitTile<NS, NA>::O_ROW + (threadIdx.x & 63u);
+            if constexpr (SPLIT) {
+                // hand obs / reward / done (and the controller's action) to the memory wavefront; it drains this
+                // half two barriers later
+                using ST_ = SplitTile<NS, NA, DRAWS>;
+                float *row = lds_w + ST_::A_WORDS + ((k / kSplitChunk) & 1) * ST_::O_HALF + (k % kSplitChunk) * ST_::O_ROW +
+                             (threadIdx.x & 63u);
                 if (obs_out) {
                     if (aos) {   // env-major for the batch-major drain
-                        float *mine = row + (threadIdx.x & 63u) * (SplitTile<NS, NA>::OBS_STRIDE - 1);
+                        float *mine = row + (threadIdx.x & 63u) * (ST_::OBS_STRIDE - 1);
 #pragma unroll
                         for (int c = 0; c < NS; ++c) mine[c] = s[c];
                     } else {
@@ -532,8 +559,14 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                         for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
                     }
                 }
-                row[SplitTile<NS, NA>::REW] = r;
-                row[SplitTile<NS, NA>::DONE] = done ? 1.0f : 0.0f;
+                row[ST_::REW] = r;
+                row[ST_::DONE] = done ? 1.0f : 0.0f;
+                if constexpr (!DRAWS) {
+                    if (a.act_out) {
+#pragma unroll
+                        for (int c = 0; c < NA; ++c) row[ST_::ACT + c * 64] = act[c];
+                    }
+                }
             } else if (obs_out) {
                 if (ST == ST_AOS_LDS && full_wave) {
                     // all 64 lanes are here (full_wave is wave-uniform); LDS executes one wavefront's
@@ -561,16 +594,16 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
                 obs_out += (int64_t)NS * n;
             }
-            if (MODE != ACT_RANDOM_SPLIT && rew_out) {
+            if (!SPLIT && rew_out) {
                 buf_st_aux<AUX>(make_rsrc(rew_out), off, 0, r);
                 rew_out += n;
             }
-            if (MODE != ACT_RANDOM_SPLIT && done_out) {
+            if (!SPLIT && done_out) {
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(done_out), li, 0, 0);
                 done_out += n;
             }
         }
-        if constexpr (MODE == ACT_RANDOM_SPLIT) __syncthreads();   // B(nc): the last chunk's outputs are in LDS
+        if constexpr (SPLIT) __syncthreads();   // B(nc): the last chunk's outputs are in LDS
 
         if constexpr (MODE == ACT_POLICY_BF16) {   // bootstrap value of the state the rollout ends in
             float x[16], mean[4], val0;

@@ -14,10 +14,11 @@ for it in range(int(os.environ.get("ITERS", "300"))):
     n = int(rng.choice([1, 63, 64, 65, 127, 1000, 10001, 20001, 65536, 70000]))
     T = int(rng.choice([8, 9, 11, 12, 31, 64, 96]))
     seed = int(rng.randint(1 << 30))
+    mode = ["random", "controller"][(it // 4) % 2]
     res = []
     for fused in (True, False):
         env = g.BatchedQuadrotor(kind, n, seed=seed, auto_reset=True, track_episodes=True)
-        tr = env.rollout(T, mode="random", layout="soa", fused=fused, want=("actions", "obs", "rew", "done"), device_out=True)
+        tr = env.rollout(T, mode=mode, layout=["soa", "aos"][(it // 8) % 2], fused=fused, want=("actions", "obs", "rew", "done"), device_out=True)
         res.append((tr, env.get_state(layout="soa", device_out=True), env.episode_totals(), env.episode_buffers(device_out=True)))
         env.close()
     (a, sa, ta, ea), (b, sb, tb, eb) = res
@@ -26,7 +27,7 @@ for it in range(int(os.environ.get("ITERS", "300"))):
     if not ok:
         bad += 1
         which = [k for k in a if not torch.equal(a[k], b[k])]
-        print("MISMATCH", it, kind, n, T, seed, which, ta, tb, flush=True)
+        print("MISMATCH", it, kind, mode, n, T, seed, which, ta, tb, flush=True)
         for k in which:
             d = (a[k] != b[k]).nonzero()
             print("  ", k, "first diffs", d[:5].tolist(), "count", len(d), flush=True)

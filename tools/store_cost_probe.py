@@ -12,9 +12,9 @@ stream = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(stream):
     for want in [(), ("rew", "done"), ("obs",), ("actions",), ("obs", "rew", "done"), ("actions", "obs", "rew", "done")]:
         env = g.BatchedQuadrotor(kind, n, seed=0, auto_reset=True, track_episodes=os.environ.get("TRACK", "0") == "1")
-        out = env.rollout(T, mode="random", want=want, device_out=True)
+        out = env.rollout(T, mode=os.environ.get("MODE", "random"), want=want, device_out=True)
         def run():
-            env.rollout(T, mode="random", want=want, device_out=True, out=out)
+            env.rollout(T, mode=os.environ.get("MODE", "random"), want=want, device_out=True, out=out)
         for _ in range(5): run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
