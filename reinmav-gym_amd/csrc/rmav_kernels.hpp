@@ -19,7 +19,9 @@
 // Gaussian MLP policy evaluated in-kernel (fp32 VALU / bf16 MFMA).
 // Per-step physics constants arrive as kernel arguments (scalar registers via s_load), not LDS: they are
 // wave-uniform, ~200 bytes, and an LDS copy would cost a barrier per launch for nothing.  LDS is used where
-// the constants are too big for SGPRs: the policy weights (30-42 KB, staged once per launch).
+// the constants are too big for SGPRs (the policy weights, 30-42 KB, staged once per launch), for the hand-over
+// tiles between the integrator and the memory wavefront of small-batch fused rollouts, and for transposing
+// batch-major obs tiles of big launches.
 #pragma once
 
 #include "rmav_math.hpp"
