@@ -178,6 +178,9 @@ def main():
         def measure(mode, chunk, K, W):
             run, per_launch = make_runner(mode, chunk)
             run(W)
+            if use_dist:   # warm the collective too (RCCL connects rings lazily on the first call of each kind)
+                eb = env.episode_buffers(device_out=True)
+                all_gather_episode_stats(eb["last_return"], eb["last_length"], n_total)
             stream.synchronize()
             if use_dist:
                 dist.barrier()
