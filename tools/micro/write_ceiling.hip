@@ -1,7 +1,7 @@
 // write_ceiling.hip - how fast can this GPU absorb the fused rollout's store pattern with no arithmetic at all?
 // (diagnostic, not part of the library).  One wavefront lane per env, T time steps, per step 15 dword columns
 // (4 action + 10 obs + 1 reward) + 1 byte column, time-major SoA exactly like k_rollout's trajectory.
-// build+run on the GPU box:  hipcc --offload-arch=gfx950 -O3 -o /tmp/wc tools/micro/write_ceiling.hip && /tmp/wc
+// build here: hipcc --offload-arch=gfx950 -O3 -o tools/micro/_build/wc tools/micro/write_ceiling.hip ; run on the GPU box: tools/micro/_build/wc
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
