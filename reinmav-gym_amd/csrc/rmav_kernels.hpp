@@ -306,6 +306,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         float4 *dst = reinterpret_cast<float4 *>(lds_w);
         for (int q = threadIdx.x; q < NW4; q += blockDim.x) dst[q] = src[q];
         __syncthreads();
+        if constexpr (MODE == ACT_POLICY_BF16) {
+            scale_biases_for_tanh();
+            __syncthreads();
+        }
     }
 
     if (li < (uint64_t)n) {

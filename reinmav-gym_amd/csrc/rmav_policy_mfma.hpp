@@ -64,12 +64,34 @@ __device__ __forceinline__ bf16x8_t ld_frag(const float *base, uint32_t lane) {
     return *reinterpret_cast<const bf16x8_t *>(base + lane * 4u);   // 16 bytes per lane
 }
 
-// registers [8 half .. 8 half + 8) of an accumulator -> tanh -> bf16 B fragment
+// tanh on the matrix-core path.  This kernel is bound by VALU throughput (256 activations per env per step), so
+// the activation is cut to four instructions: with zk = k z, k = 2 log2(e),
+//     tanh(z) = 1 - 2 / (1 + 2^zk)            v_exp_f32, v_add_f32, v_rcp_f32, v_fma_f32
+// and the factor k never costs a multiply: the pre-activations arrive already scaled - layer 1 multiplies the state
+// by k before it is rounded to bf16 and layer 2 receives k tanh() (the same fma with constants (-2k, k)), while the
+// biases of both layers are scaled once when the weights are staged into LDS (kTanhScale, scale_biases_for_tanh).
+// Saturates cleanly (2^zk = inf -> 1, 0 -> -1); absolute error ~1e-7, far below the bf16 rounding of the result.
+constexpr float kTanhScale = 2.8853900817779268f;   // 2 log2(e)
+
+// registers [8 half .. 8 half + 8) of an accumulator holding k z -> (A tanh(z) ... ) as a bf16 B fragment:
+// OUT_SCALE = k for the fragment that feeds layer 2, 1 for the one that feeds the output layer
+template <bool SCALED_OUT>
 __device__ __forceinline__ bf16x8_t act_frag(const f32x16_t &acc, int half) {
+    constexpr float A = SCALED_OUT ? -2.0f * kTanhScale : -2.0f, B = SCALED_OUT ? kTanhScale : 1.0f;
     bf16x8_t b;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = (__bf16)tanh_fast(acc[8 * half + j]);
+    for (int j = 0; j < 8; ++j) {
+        const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + j]));
+        b[j] = (__bf16)__builtin_fmaf(r, A, B);
+    }
     return b;
+}
+
+// The fp32 bias tables of layers 1 and 2 of both nets, scaled by k in place (called once per launch by the
+// threads of the block, between two barriers, right after the weights were copied into LDS).
+__device__ __forceinline__ void scale_biases_for_tanh() {
+    for (int q = threadIdx.x; q < 256; q += blockDim.x)
+        lds_w[(q >> 7) * MfmaLayout::NET + MfmaLayout::B1 + (q & 127)] *= kTanhScale;
 }
 
 // One net (weights at float offset `net` of lds_w) for the two column tiles of this wavefront.
@@ -96,7 +118,7 @@ __device__ __noinline__ MlpOut mlp_mfma(bf16x8_t b_in0, bf16x8_t b_in1, uint32_t
 #pragma unroll
     for (int Nt = 0; Nt < 2; ++Nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag(acc[s >> 1][Nt], s & 1);
+        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag<true>(acc[s >> 1][Nt], s & 1);
     f32x16_t acc2[2][2];
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
@@ -114,7 +136,7 @@ __device__ __noinline__ MlpOut mlp_mfma(bf16x8_t b_in0, bf16x8_t b_in1, uint32_t
 #pragma unroll
     for (int Nt = 0; Nt < 2; ++Nt)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag(acc2[s >> 1][Nt], s & 1);
+        for (int s = 0; s < 4; ++s) hb[Nt][s] = act_frag<false>(acc2[s >> 1][Nt], s & 1);
     f32x16_t o0 = bias_frag(w + L::B3, h), o1 = o0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -140,8 +162,9 @@ __device__ __forceinline__ void policy_forward_mfma(const float (&x)[16], float 
     bf16x8_t own, other;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float mine = h ? x[8 + j] : x[j];        // x[8h + j]
-        const float send = h ? x[j] : x[8 + j];        // x[8(1-h) + j]: what the partner's fragment needs
+        // (the state is pre-multiplied by k = 2 log2 e so that layer 1's accumulators hold k z, see act_frag)
+        const float mine = kTanhScale * (h ? x[8 + j] : x[j]);        // x[8h + j]
+        const float send = kTanhScale * (h ? x[j] : x[8 + j]);        // x[8(1-h) + j]: what the partner's fragment needs
         const float recv = __shfl_xor(send, 32, 64);
         own[j] = (__bf16)mine;
         other[j] = (__bf16)recv;
