@@ -78,13 +78,20 @@ constexpr float kTanhScale = 2.8853900817779268f;   // 2 log2(e)
 template <bool SCALED_OUT>
 __device__ __forceinline__ bf16x8_t act_frag(const f32x16_t &acc, int half) {
     constexpr float A = SCALED_OUT ? -2.0f * kTanhScale : -2.0f, B = SCALED_OUT ? kTanhScale : 1.0f;
-    bf16x8_t b;
+    // explicit pairs: one v_cvt_pk_bf16_f32 per two activations, the four dwords are the fragment (left to itself
+    // hipcc converted some values singly and re-paired them with v_alignbit / v_perm: +25 % VALU in this function)
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    u32x4_t packed;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + j]));
-        b[j] = (__bf16)__builtin_fmaf(r, A, B);
+    for (int j = 0; j < 4; ++j) {
+        f32x2_t v;
+        v[0] = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + 2 * j])), A, B);
+        v[1] = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + 2 * j + 1])), A, B);
+        packed[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
     }
-    return b;
+    return __builtin_bit_cast(bf16x8_t, packed);
 }
 
 // The fp32 bias tables of layers 1 and 2 of both nets, scaled by k in place (called once per launch by the
