@@ -41,11 +41,11 @@ template <int NS> struct PolicyLayout {
     static constexpr int TOTAL = 2 * NET + 4;   // floats in the whole buffer
 };
 
-// tanh(x) = sign(x) * (1 - e) / (1 + e),  e = exp(-2|x|) ; |abs error| < 3e-7, no branches
+// tanh(x) = 1 - 2 / (1 + 2^(k x)),  k = 2 log2(e): v_mul, v_exp, v_add, v_rcp, v_fma.  No branches; saturates cleanly
+// (2^(kx) = inf -> 1, 0 -> -1); |abs error| < 2e-7.
 __device__ __forceinline__ float tanh_fast(float x) {
-    const float e = __expf(-2.0f * __builtin_fabsf(x));
-    const float t = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
-    return __builtin_copysignf(t, x);
+    const float t = __builtin_amdgcn_exp2f(2.8853900817779268f * x);
+    return __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + t), -2.0f, 1.0f);
 }
 
 // out[0..3] = W3 . tanh(W2 . tanh(W1 . x + b1) + b2) + b3   for one net whose weights start at `w` in LDS.
