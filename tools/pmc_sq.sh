@@ -8,7 +8,7 @@ REPO=$PWD
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z0-9_]+|GRBM_[A-Z_]+|TCP_[A-Z0-9_]+|TCC_[A-Z0-9_]+)\b" | sort -u > $OUT/counters.txt
 wc -l $OUT/counters.txt
-B="python $REPO/bench.py --no-secondary --cpu-seconds 0 --steps 20 --warmup 2 $EXTRA"
+B="python $REPO/bench.py --no-secondary --cpu-seconds 0 --steps 60 --warmup 40 $EXTRA"
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_LDS" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_INSTS_VMEM_RD" \
