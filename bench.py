@@ -4,25 +4,34 @@
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched under
 ``python -m torch.distributed.run --nproc-per-node N``.  Rank 0 prints ONE JSON line.
 
-Workload (BASELINE.json configs[1], per GPU): quadrotor3d-v0, 65 536 envs, random actions
-T~U[0,10), w~U[0,10)^3 drawn in-kernel from the counter RNG, auto-reset on done, episode tracking on.
-One bench "step" = ONE launch of the hot-path kernel over the whole batch:
+Workload (BASELINE.json configs): quadrotor3d-v0, random actions T~U[0,10), w~U[0,10)^3 drawn in-kernel from the
+counter RNG, auto-reset on done, episode tracking on.
+  N = 1 : configs[1] (C2) - 65 536 envs on the GPU.
+  N > 1 : configs[2] (C3) - 131 072 envs per GPU, sharded by GLOBAL env id (N = 8 is exactly C3's 1 048 576 envs).
+One bench "step" = ONE launch of the hot-path kernel over the rank's whole shard:
 
   --mode rollout (default): the fused rollout kernel advances every env ``--chunk`` (64) env-steps with the
-      state held in registers and writes the full trajectory (actions, obs, reward, done per env-step)
-      to HBM - the unit an RL learner consumes.
+      state held in registers and writes the full trajectory (actions, obs, reward, done per env-step) to HBM -
+      the unit an RL learner consumes.  Every launch writes the NEXT buffer set of a ring (>= 5 sets, > 1.5 GB:
+      what a learner double-buffering real rollouts does), so no store is absorbed by rewriting lines that
+      still sit in the 256 MiB Infinity Cache.  ``--in-place`` rewrites one set every launch instead.
   --mode step: the same kernel at chunk = 1, one launch per env-step: actions read from a device buffer
       (what a policy would have written), state updated in place (obs == state), reward/done written.
 
-value = (envs on all ranks) * chunk * K / max-over-ranks wall time of the K timed launches (inputs
-already resident in HBM; barrier + synchronize on both sides).  For N > 1 the env batch is sharded by
-global env id (weak scaling: 65 536 envs per GPU) and the timed region ends with the one collective the
-path has: the RCCL all-gather of per-env episode returns/lengths.
+value = (envs on all ranks) * chunk * K / max-over-ranks wall time of the K timed launches (inputs already
+resident in HBM; barrier + synchronize on both sides).  For N > 1 every rollout launch is followed by the one
+collective the path has: the RCCL all-gather of per-env episode returns/lengths (packed by one small launch,
+gathered on a second stream so that it overlaps the next rollout).
 
-roofline: algorithmic bytes per env-step (read state + read action + write state + write
-reward + write done = 101 B for quadrotor3d) * env-steps per launch / average launch duration measured
-with HIP events on the launch stream, against 8 TB/s.  cpu_baseline: the C oracle (oracle/, a port of
-the reference's NumPy step) timed on one host core over a bounded sample of the same workload.
+roofline (dominant kernel = the timed launch; duration from HIP events on the launch stream):
+  rollout: bytes the fused kernel must move per launch = N * (chunk * (4 (nS + nA + 1) + 1) + 8 nS + 24)
+           (trajectory out: obs + actions + reward f32, done u8; per launch: state in/out, episode accumulators
+           in/out, steps_beyond_done + reset counter in) - SURVEY 8d's "fused-rollout variant".  The state
+           stays in registers between steps, so the 101 B/env-step of the single-step definition would count
+           80 B that never move; that figure is reported beside it as ``algorithmic_equiv_frac``.
+  step:    SURVEY 8d's 4 (2 nS + nA + 1) + 1 = 101 B per env-step.
+cpu_baseline: the C oracle (oracle/, a port of the reference's NumPy step) timed on host cores over a bounded
+sample of the same workload.
 """
 from __future__ import annotations
 
@@ -36,6 +45,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "reinmav-gym_amd"))
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s HBM3E
+ENV_ID = {"quad3d": "quadrotor3d-v0", "quad3d_sl": "quadrotor3d-slungload-v0", "quad2d": "quadrotor2d-v0",
+          "quad2d_sl": "quadrotor2d-slungload-v0", "reinmav": "reinmav-v0"}
 
 
 def _omp_set_threads(k: int):
@@ -85,30 +96,40 @@ def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: 
     }
 
 
+def fused_bytes_per_launch(n: int, chunk: int, nS: int, nA: int) -> int:
+    """What one fused rollout launch must move (see the module docstring)."""
+    return n * (chunk * (4 * (nS + nA + 1) + 1) + 8 * nS + 24)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000,
-                    help="timed launches (SURVEY 8d asks for >= 1000 after >= 100 warm-up; 2000 launches ~ 0.1 s)")
+                    help="timed launches (SURVEY 8d asks for >= 1000 after >= 100 warm-up; 2000 launches ~ 0.1-0.2 s)")
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--kind", default="quad3d", choices=["quad2d", "quad2d_sl", "quad3d", "quad3d_sl", "reinmav"])
     ap.add_argument("--actions", default="random", choices=["random", "controller"],
                     help="action source of the fused rollout (controller = the reference's built-in / geometric controller)")
-    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--envs-per-gpu", type=int, default=None,
+                    help="default: 65536 on one GPU (BASELINE C2), 131072 per GPU on several (C3's shard)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--chunk", type=int, default=64,
                     help="env-steps per launch in rollout mode (64 amortises the ~4.5 us fixed cost of a launch; "
                          "see profiles/*/sweep_kinds_sizes.md for 8..128)")
     ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
+    ap.add_argument("--in-place", action="store_true", help="rollout mode: rewrite ONE trajectory buffer set (cache-assisted)")
+    ap.add_argument("--ring", type=int, default=0, help="rollout mode: number of trajectory buffer sets (0 = >= 5 and > 1.5 GB)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the other mode's short measurement")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
+    ap.add_argument("--secondary", default="in_place,step,gym1,vecenv,policy",
+                    help="comma list of the other measurements to add under other_modes (single process only)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
 
     import gym_reinmav_amd as g
-    from gym_reinmav_amd.distributed import all_gather_episode_stats, all_reduce_totals
+    from gym_reinmav_amd.distributed import EpisodeStatsExchange, all_reduce_totals
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,45 +141,76 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # several ranks on one GPU (the two-process test on a 1-GPU box) share device 0
+    local_dev = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("RMAV_BENCH_BACKEND", "nccl")   # "gloo": ranks sharing one GPU (RCCL refuses duplicates)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     torch.manual_seed(0)  # the step mode's action ring is filled by torch's generator
     kind = args.kind
-    n = args.envs_per_gpu
+    n = args.envs_per_gpu if args.envs_per_gpu else (65536 if world == 1 else 131072)
     n_total = n * world
     A = g._abi
-    nS, nA = A.STATE_DIM[A.KIND_BY_NAME[kind]], A.ACTION_DIM[A.KIND_BY_NAME[kind]]
-    algo_bytes = A.lib().rmav_algorithmic_bytes(A.KIND_BY_NAME[kind])
-    p = A.default_params(A.KIND_BY_NAME[kind])
+    K_ = A.KIND_BY_NAME[kind]
+    nS, nA = A.STATE_DIM[K_], A.ACTION_DIM[K_]
+    algo_bytes = A.lib().rmav_algorithmic_bytes(K_)
+    p = A.default_params(K_)
     lo, hi = float(p.act_lo), float(p.act_hi)
 
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        env = g.BatchedQuadrotor(kind, n, device=local_rank, seed=0, env_id_base=rank * n, auto_reset=True,
+        env = g.BatchedQuadrotor(kind, n, device=local_dev, seed=0, env_id_base=rank * n, auto_reset=True,
                                  track_episodes=True)
+        gloo = use_dist and dist.get_backend() == "gloo"
+        exchange = EpisodeStatsExchange(n_total, "cpu" if gloo else dev) if use_dist else None
 
         RING = 512  # step mode: ring of pre-generated action buffers (fresh random actions every launch)
 
-        def make_runner(mode, chunk):
-            """Returns (run(k): enqueue k launches, env-steps per env per launch)."""
+        def traj_bytes(chunk):
+            return n * chunk * (4 * (nS + nA + 1) + 1)
+
+        def ring_size(chunk, in_place):
+            if in_place:
+                return 1
+            if args.ring > 0:
+                return args.ring
+            r = max(5, -(-int(1.5e9) // traj_bytes(chunk)))
+            while r > 2 and r * traj_bytes(chunk) > 64e9:   # stay far below 288 GB for multi-million-env sweeps
+                r -= 1
+            return r
+
+        def make_runner(mode, chunk, in_place=False):
+            """Returns (run(k): enqueue k launches, env-steps per env per launch, buffer sets)."""
             if mode == "rollout":
                 shp = (lambda d: (chunk, d, n)) if args.layout == "soa" else (lambda d: (chunk, n, d))
-                bufs = {
+                R = ring_size(chunk, in_place)
+                ring = [{
                     "actions": torch.empty(shp(nA), dtype=torch.float32, device=dev),
                     "obs": torch.empty(shp(nS), dtype=torch.float32, device=dev),
                     "rew": torch.empty((chunk, n), dtype=torch.float32, device=dev),
                     "done": torch.empty((chunk, n), dtype=torch.uint8, device=dev),
-                }
+                } for _ in range(R)]
+                it = [0]
 
                 def run(k):
                     for _ in range(k):
                         env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
-                                    want=("actions", "obs", "rew", "done"), device_out=True, out=bufs)
-                return run, chunk
+                                    want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
+                        it[0] += 1
+                        if exchange is not None:   # the path's one exchange, once per rollout
+                            if gloo:
+                                eb = env.episode_buffers()
+                                exchange.post(torch.from_numpy(eb["last_return"]), torch.from_numpy(eb["last_length"]))
+                            else:
+                                exchange.post(env=env)
+                return run, chunk, R
             # step mode: one launch per env-step; the launch loop runs inside librmav (rmav_rollout with
             # fused=0), so Python/ctypes overhead is paid once per RING launches.  State is updated in
             # place (obs == state, as SURVEY.md 8d defines the 101 algorithmic bytes); reward and done
@@ -173,14 +225,11 @@ def main():
                     env.rollout(m, mode="buffer", actions=ring[:m], layout="soa", fused=False, want=("rew", "done"),
                                 out={"rew": bufs["rew"][:m], "done": bufs["done"][:m]})
                     k -= m
-            return run, 1
+            return run, 1, 1
 
-        def measure(mode, chunk, K, W):
-            run, per_launch = make_runner(mode, chunk)
+        def measure(mode, chunk, K, W, in_place=False):
+            run, per_launch, R = make_runner(mode, chunk, in_place)
             run(W)
-            if use_dist:   # warm the collective too (RCCL connects rings lazily on the first call of each kind)
-                eb = env.episode_buffers(device_out=True)
-                all_gather_episode_stats(eb["last_return"], eb["last_length"], n_total)
             stream.synchronize()
             if use_dist:
                 dist.barrier()
@@ -190,50 +239,85 @@ def main():
             e0.record(stream)
             run(K)
             e1.record(stream)
-            gathered = None
-            if use_dist:  # the path's one exchange: per-rollout all-gather of episode statistics (RCCL / xGMI)
-                eb = env.episode_buffers(device_out=True)
-                gathered = all_gather_episode_stats(eb["last_return"], eb["last_length"], n_total)
+            gathered = exchange.result() if (exchange is not None and mode == "rollout") else None
             torch.cuda.synchronize()
             if use_dist:
                 dist.barrier()
             wall = time.perf_counter() - t0
             kernel_ms = e0.elapsed_time(e1) / K  # HIP events on the launch stream
             if use_dist:
-                w = torch.tensor([wall], dtype=torch.float64, device=dev)
+                w = torch.tensor([wall], dtype=torch.float64, device="cpu" if gloo else dev)
                 dist.all_reduce(w, op=dist.ReduceOp.MAX)
                 wall = float(w.item())
-                assert gathered[0].numel() == n_total
-            return wall, kernel_ms, per_launch
+                if gathered is not None:
+                    assert gathered[0].numel() == n_total and gathered[1].numel() == n_total
+            return wall, kernel_ms, per_launch, R, gathered
 
-        secondary = None
-        if not args.no_secondary:   # the other mode, for the record (every rank runs it: it contains collectives)
-            other = "step" if args.mode == "rollout" else "rollout"
-            K2 = 4000 if other == "step" else 500
-            w2, k2, pl2 = measure(other, args.chunk, K2, 200 if other == "step" else 50)
-            secondary = {"mode": other, "launches": K2, "env_steps_per_launch": n * pl2,
-                         "value": n_total * pl2 * K2 / w2, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * w2 / K2,
-                         "ms_per_launch_hip_events": k2,
-                         "roofline_frac": algo_bytes * n * pl2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        other = {}
+        single = not use_dist and not args.no_secondary
+        sec = set(args.secondary.split(",")) if single else set()
+        if "step" in sec or "in_place" in sec:
+            if args.mode == "rollout" and "step" in sec:
+                w2, k2, pl2, _, _ = measure("step", 1, 4000, 200)
+                other["step"] = {"launches": 4000, "env_steps_per_launch": n, "value": n * 4000 / w2, "unit": "env-steps/s",
+                                 "ms_per_launch_wall": 1e3 * w2 / 4000, "ms_per_launch_hip_events": k2,
+                                 "bytes_per_env_step": algo_bytes,
+                                 "roofline_frac": algo_bytes * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if args.mode == "rollout" and "in_place" in sec and not args.in_place:
+                w2, k2, pl2, _, _ = measure("rollout", args.chunk, 500, 100, in_place=True)
+                b2 = fused_bytes_per_launch(n, args.chunk, nS, nA)
+                other["rollout_in_place"] = {
+                    "note": "one trajectory buffer set rewritten every launch: at 65 536 envs its 256 MB sit in the "
+                            "256 MiB Infinity Cache, so the stores are cache-assisted (round 1's headline)",
+                    "launches": 500, "value": n * pl2 * 500 / w2, "unit": "env-steps/s", "ms_per_launch_hip_events": k2,
+                    "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
-        # after idle run ~15 % slower on these boxes - 50.9 vs 43.1 us per launch measured with K=100 / K=1000 -
-        # so the defaults are sized well past that.)
-        wall, kernel_ms, per_launch = measure(args.mode, args.chunk, args.steps, args.warmup)
+        # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
+        wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place)
         totals = env.episode_totals()
         if use_dist:
-            totals = all_reduce_totals(totals, device=dev)
+            totals = all_reduce_totals(totals, device="cpu" if gloo else dev)
+        if gathered is not None:
+            gathered_finished = int((gathered[1] > 0).sum().item())
+        else:   # single process: the same statistic from the local per-env buffers
+            gathered_finished = int((env.episode_buffers()["last_length"] > 0).sum())
+
+    if single:
+        try:
+            if "gym1" in sec:
+                other["gym1"] = bench_gym1()
+            if "vecenv" in sec:
+                other["vecenv"] = bench_vecenv(dev, n)
+            if "policy" in sec and kind != "reinmav":
+                other["policy_rollout"] = bench_policy(dev, kind, n)
+        except Exception as e:  # pragma: no cover - never lose the headline line to a secondary leg
+            other["error"] = repr(e)
 
     value = n_total * per_launch * args.steps / wall
-    achieved = algo_bytes * n * per_launch / (kernel_ms * 1e-3) / 1e9  # GB/s, one GPU's dominant kernel
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # PMC-derived HBM bytes/launch (see profiles/README.md)
+    if args.mode == "rollout":
+        bytes_launch = fused_bytes_per_launch(n, per_launch, nS, nA)
+        bytes_def = (f"{n} envs x ({per_launch} env-steps x {4 * (nS + nA + 1) + 1} B trajectory out + {8 * nS + 24} B "
+                     "state / episode bookkeeping per launch)")
+    else:
+        bytes_launch = algo_bytes * n
+        bytes_def = f"{n} envs x {algo_bytes} B (SURVEY 8d: state in/out, action in, reward + done out)"
+    achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9  # GB/s, one GPU's dominant kernel
+    tkey = f"{kind}:{args.mode}:{per_launch}:{n}:{'inplace' if (args.in_place or args.mode == 'step') else 'ring'}:{args.actions}:{args.layout}"
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # rocprofv3 --pmc bytes per launch of this very command line
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{kind}:{args.mode}:{args.chunk if args.mode == 'rollout' else 1}:{n}")
+            ent = json.load(open(tpath)).get(tkey)
+            if ent:
+                traffic, traffic_src = float(ent["bytes"]), ent.get("source")
         except Exception:
             traffic = None
 
     if rank == 0:
+        cfg_name = ("BASELINE configs[1] (C2)" if (world == 1 and n == 65536 and kind == "quad3d") else
+                    f"BASELINE configs[2] (C3: {n_total} envs over {world} GPUs)" if (n == 131072 and kind == "quad3d" and world == 8) else
+                    "BASELINE configs[2]'s per-GPU shard (131 072 envs per GPU)" if (n == 131072 and kind == "quad3d") else
+                    "BASELINE configs[3] (C4)" if (world == 1 and n == 262144 and kind == "quad3d_sl") else "custom")
         line = {
             "metric": "env-steps/sec (batched quadrotor3d-v0)" if kind == "quad3d" else f"env-steps/sec (batched {kind})",
             "value": value,
@@ -248,19 +332,25 @@ def main():
             "dtype": "f32" if kind in ("quad2d", "quad3d") else "f64 arithmetic on f32 storage",
             "data": "synthetic",
             "config": {
-                "workload": (f"{ {'quad3d': 'quadrotor3d-v0', 'quad3d_sl': 'quadrotor3d-slungload-v0', 'quad2d': 'quadrotor2d-v0', 'quad2d_sl': 'quadrotor2d-slungload-v0', 'reinmav': 'reinmav-v0'}[kind]}"
-                             f", {n} envs per GPU, random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
+                "workload": (f"{cfg_name}: {ENV_ID[kind]}, {n} envs per GPU ({n_total} total, global env ids {rank * n}.. per rank), "
+                             f"random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
                              + (f"one step = one fused rollout launch = {per_launch} env-steps per env, in-kernel action source '{args.actions}', "
-                                "trajectory (actions, obs, reward, done) written to HBM" if args.mode == "rollout"
+                                f"trajectory (actions, obs, reward, done) written to HBM into "
+                                + ("ONE buffer set rewritten in place" if R == 1 else f"a ring of {R} buffer sets ({R * traj_bytes(per_launch) / 1e9:.2f} GB: cold stores)")
+                                if args.mode == "rollout"
                                 else "one step = one launch = 1 env-step per env, actions read from a device buffer, "
                                      "obs/reward/done written")),
                 "envs_per_gpu": n,
+                "envs_total": n_total,
                 "env_steps_per_launch_per_env": per_launch,
                 "mode": args.mode,
                 "trajectory_layout": args.layout if args.mode == "rollout" else "soa",
-                "parallelism": f"env-shard x{world} (global env ids; one RCCL all-gather of episode stats per timed region)"
-                if world > 1 else "single GPU",
+                "trajectory_ring": R,
+                "parallelism": (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one RCCL all-gather of "
+                                "per-env episode stats after EVERY rollout launch, overlapped with the next launch on a second stream)")
+                if use_dist else "single GPU",
                 "finished_episodes": totals["episodes"],
+                "gathered_envs_with_a_finished_episode": gathered_finished,
             },
             "roofline": {
                 "bound": "hbm",
@@ -269,18 +359,21 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                # the physical side of the same launch: PMC bytes / measured duration (the fused kernel keeps the state
-                # in registers, so it moves fewer bytes than the algorithmic definition counts and `frac` can exceed 1)
-                "traffic_achieved": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+                "traffic_source": traffic_src,
                 "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "algorithmic_bytes_per_env_step": algo_bytes,
-                "env_steps_per_launch": n * per_launch,
+                "bytes_per_launch": bytes_launch,
+                "bytes_definition": bytes_def,
                 "launch_ms_hip_events": kernel_ms,
+                "env_steps_per_launch": n * per_launch,
+                # the single-step definition applied to the fused launch (it counts 8 nS bytes of state in/out per
+                # env-step that the fused kernel keeps in registers): a speed-up-equivalent, NOT an HBM fraction
+                "algorithmic_equiv_bytes_per_env_step": algo_bytes,
+                "algorithmic_equiv_frac": algo_bytes * n * per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
         }
-        if secondary:
-            line["other_mode"] = secondary
-        if world == 1 and args.cpu_seconds > 0 and kind != "reinmav":
+        if other:
+            line["other_modes"] = other
+        if world == 1 and not use_dist and args.cpu_seconds > 0 and kind != "reinmav":
             line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             if ncpu > 1:
@@ -310,6 +403,114 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ---- the boundaries the reference's callers use (reported under other_modes) ---------------------------------------
+def bench_gym1(episodes: int = 12):
+    """BASELINE configs[0] (C1): quadrotor2d-v0, ONE env behind the gym.Env interface, the loop of the reference's
+    test/test_quadrotor2d.py:11-24 - 400 x (action = env.control(); env.step(action); reset on done) - timed with a
+    monotonic clock around the loop exactly as the reference does.  Reference (authoring container):
+    59 us per step() alone."""
+    import gym_reinmav_amd as g
+
+    env = g.make("quadrotor2d-v0")
+    env.reset()
+    for _ in range(400):   # warm-up: first launches, pinned block
+        a = env.control()
+        _, _, d, _ = env.step(a)
+        if d:
+            env.reset()
+    best, tot, its = None, 0.0, 0
+    for _ in range(episodes):
+        env.reset()
+        t0 = time.perf_counter()
+        for _ in range(400):
+            action = env.control()
+            _, reward, done, _ = env.step(action)
+            if done:
+                env.reset()
+        el = time.perf_counter() - t0
+        tot += el
+        its += 400
+        best = el if best is None or el < best else best
+    # step() alone with a constant action (what BASELINE.md section 2 timed for the reference)
+    a = env.control()
+    env.reset()
+    t0 = time.perf_counter()
+    for _ in range(2000):
+        _, _, d, _ = env.step(a)
+        if d:
+            env.reset()
+    st = (time.perf_counter() - t0) / 2000
+    env.close()
+    return {"workload": "quadrotor2d-v0, batch = 1, gym.Env API, 400 x (control(); step(); reset on done) per episode "
+                        "(test/test_quadrotor2d.py:11-24), host NumPy in / out",
+            "us_per_iteration_control_plus_step": 1e6 * tot / its, "us_per_iteration_best_episode": 1e6 * best / 400,
+            "us_per_step_alone": 1e6 * st, "episodes": episodes,
+            "reference_us_per_step": 59.0, "reference_source": "BASELINE.md section 2 (reference NumPy step(), authoring container)"}
+
+
+def bench_vecenv(dev, n: int, iters: int = 3000):
+    """The VecEnv contract baselines reaches through make_vec_env (gym_reinmav/run.py:89): QuadrotorVecEnv.step with
+    device tensors, one env-step per call, Python in the loop."""
+    import torch
+
+    import gym_reinmav_amd as g
+
+    out = {"workload": f"QuadrotorVecEnv('quadrotor3d-v0', {n}).step(actions[N,4] device tensor) -> (obs, rew, done, infos), "
+                       "auto-reset, one launch per call"}
+    for reuse in (False, True):
+        venv = g.QuadrotorVecEnv("quadrotor3d-v0", n, device=dev.index, seed=0, reuse_buffers=reuse)
+        venv.reset()
+        act = torch.empty((n, 4), dtype=torch.float32, device=dev).uniform_(0.0, 10.0)
+        for _ in range(200):
+            venv.step(act)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            venv.step(act)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        out["reuse_buffers" if reuse else "fresh_tensors_per_step"] = {"us_per_step": 1e6 * el / iters,
+                                                                      "env_steps_per_s": n * iters / el}
+        venv.close()
+    return out
+
+
+def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
+    """BASELINE configs[4] (C5)'s per-GPU shape: 65 536 envs x 32-step PPO2-style rollouts with the Gaussian MLP policy
+    and value net evaluated inside the rollout kernel (rmav_rollout_policy), plus the GAE pass over the result."""
+    import torch
+
+    import gym_reinmav_amd as g
+    from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
+
+    out = {"workload": f"{ENV_ID[kind]}, {n} envs x {T}-step rollouts, 2x64 tanh MLP policy + value net in-kernel, "
+                       "trajectory + logp + values written to HBM; then rmav_gae over the [T][N] result"}
+    for bf16 in (False, True):
+        torch.manual_seed(0)
+        env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        pol = MlpPolicy(env.nS, env.nA).to(dev)
+        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=bf16)
+        adv, ret = torch.empty_like(ro.rew), torch.empty_like(ro.rew)
+        sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        for _ in range(5):
+            ro.collect()
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        for _ in range(iters):
+            ro.collect()
+        e1.record()
+        for _ in range(iters):
+            env.gae(ro.rew, ro.done, ro.val, out=(adv, ret), sums=sums)
+        e2.record()
+        torch.cuda.synchronize()
+        ms_ro, ms_gae = e0.elapsed_time(e1) / iters, e1.elapsed_time(e2) / iters
+        out["bf16_mfma" if bf16 else "fp32"] = {"ms_per_rollout_incl_weight_pack": ms_ro, "env_steps_per_s": n * T / (ms_ro * 1e-3),
+                                                "gae_ms": ms_gae, "gae_GBps": 17.0 * n * T / (ms_gae * 1e-3) / 1e9}
+        env.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -21,6 +21,9 @@
  *                                   quadrotor2d_slungload.py:79-154
  *   .control()                      quadrotor3d.py:126-180        rmav_control
  *                                   quadrotor2d.py:115-138
+ *   one iteration "action = env.control(); env.step(action)" of the reference's smoke tests
+ *                                   test/test_quadrotor2d.py:17-18  rmav_control_step (one launch), or rmav_step_control
+ *                                   test/test_quadrotor3d.py:16-17  (step + the NEXT control() in one launch)
  *   .state / .steps_beyond_done     quadrotor3d.py:104,68         rmav_get_state / rmav_set_state,
  *                                                                 rmav_get_sbd / rmav_set_sbd
  *   the test loop "control -> step -> reset on done"              rmav_rollout(RMAV_ACT_CONTROLLER)
@@ -29,6 +32,9 @@
  *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM)
  *   baselines ppo2 Runner.run(): model.step(obs) + env.step(a)    rmav_rollout_policy
  *   baselines Monitor episode statistics (info['episode'])        rmav_episode_totals / _buffers
+ *   baselines ppo2 Runner.run() advantage pass (GAE lambda)       rmav_gae, rmav_normalize
+ *   MPI rank probe / data-parallel workers gym_reinmav/run.py:18-21,177-182
+ *                                                                 rmav_comm_* + rmav_allgather_stats (RCCL over xGMI)
  *
  * INTEGRATION.md shows the ctypes stub a reference maintainer would add.
  *
@@ -39,7 +45,9 @@
  *   - a handle owns the device-resident env state (fp32, struct-of-arrays) of N independent envs on
  *     one GPU and one HIP stream; it is NOT thread-safe; distinct handles are independent.
  *   - `mem` says where every caller-supplied pointer of that call lives: RMAV_HOST (the library
- *     stages through device buffers and synchronises before returning) or RMAV_DEVICE (HIP device
+ *     stages - calls that move <= 256 KiB go zero-copy through a pinned, device-mapped block owned by the
+ *     handle: one launch + one synchronise, which is what the gym-shaped single env uses; bulk calls go
+ *     through device scratch - and synchronises before returning) or RMAV_DEVICE (HIP device
  *     pointers, e.g. torch tensor data_ptr(); work is enqueued on the handle's stream and the call
  *     returns without synchronising).
  *   - `layout`: RMAV_SOA = [dim][N] (component-major, the native device layout, coalesced) or
@@ -188,6 +196,18 @@ int rmav_step(rmav_handle h, const float *actions, float *obs_out, float *rew_ou
 /* Geometric controller: actions_out (nA*N floats) <- control(state). */
 int rmav_control(rmav_handle h, float *actions_out, int mem, int layout);
 
+/* One iteration of the reference's test loop (test/test_quadrotor3d.py:16-17: action = env.control();
+ * env.step(action)) in ONE launch: actions_out (nullable) receives the controller's action, the other outputs
+ * are those of rmav_step.  Same results as rmav_control followed by rmav_step. */
+int rmav_control_step(rmav_handle h, float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out,
+                      int mem, int layout);
+/* rmav_step, and the launch ends by evaluating control() on the state it leaves behind: next_actions_out
+ * (nA*N floats, required) = what rmav_control would return if called next.  Lets a gym-shaped caller that
+ * alternates control() / step(action) pay one launch + one synchronise per iteration (the class caches the
+ * action).  Quadrotor kinds only. */
+int rmav_step_control(rmav_handle h, const float *actions, float *obs_out, float *rew_out, uint8_t *done_out,
+                      float *next_actions_out, int mem, int layout);
+
 /* n_steps steps of all N envs.  fused != 0: one kernel launch with the state held in registers
  * across the steps; fused == 0: n_steps launches of the single-step kernel (same results).
  * actions_in: [n_steps][nA][N] for RMAV_ACT_BUFFER, otherwise ignored (may be NULL).
@@ -225,6 +245,41 @@ int64_t rmav_policy_weight_count_bf16(void);
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision);
+
+/* ---- learner-side passes over a trajectory (DEVICE pointers, enqueued on the handle's stream) -------- */
+/* Generalised advantage estimation, the backward pass of baselines ppo2 Runner.run():
+ *   delta_t = reward_scale * r_t + gamma V_{t+1} (1 - done_t) - V_t,  A_t = delta_t + gamma lam (1 - done_t) A_{t+1}
+ * rew [n_steps][N], done u8 [n_steps][N] (1 = the episode ended with step t), values [n_steps + 1][N]
+ * (values[n_steps] = bootstrap value; exactly what rmav_rollout_policy writes); adv_out, ret_out [n_steps][N]
+ * (ret = A + V).  sums_out (nullable): 2 doubles on the device <- (sum A, sum A^2) over all n_steps*N samples,
+ * for the advantage normalisation (all-reduce them across ranks first when data parallel).  fp32 FMAs;
+ * agrees with a float64 per-env recursion to ~1e-6 relative. */
+int rmav_gae(rmav_handle h, int32_t n_steps, const float *rew, const uint8_t *done, const float *values,
+             float gamma, float lam, float reward_scale, float *adv_out, float *ret_out, double *sums_out);
+/* x[i] <- (x[i] - mean) * rstd for i < count (x 16-byte aligned): advantage normalisation in place. */
+int rmav_normalize(rmav_handle h, float *x, int64_t count, float mean, float rstd);
+
+/* ---- multi-GPU: the path's one collective ------------------------------------------ */
+/* Envs shard over ranks by contiguous ranges of GLOBAL env id: rank r of W owns base + (r < rem) envs
+ * starting at r*base + min(r, rem), base = n_total / W, rem = n_total % W (create each rank's handle with
+ * env_id_base = that start).  The data path needs no communication; the only exchange is the all-gather of
+ * per-env episode statistics once per rollout.  The communicator wraps an RCCL communicator (librccl.so.1 is
+ * loaded on first use; one process per GPU).  Rank 0 calls rmav_comm_unique_id and hands the 128 bytes to the
+ * other ranks out of band (file, MPI, a torch store ...); every rank then calls rmav_comm_create. */
+typedef struct rmav_comm_s *rmav_comm;
+#define RMAV_COMM_ID_BYTES 128
+int rmav_comm_unique_id(void *id_out /* RMAV_COMM_ID_BYTES bytes, host */);
+int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device);
+int rmav_comm_destroy(rmav_comm c);
+/* returns_out f32 [n_total], lengths_out i32 [n_total] (DEVICE pointers) <- return / length of every env's most
+ * recently finished episode, in global env order, on every rank.  Enqueued on the handle's stream (pack ->
+ * ncclAllGather over xGMI -> unpack); does not synchronise.  Needs RMAV_F_TRACK_EPISODES. */
+int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
+/* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
+ * send_out i32 [2][cmax] (DEVICE) <- bit patterns of the per-env last returns, then the last lengths, zero padded
+ * from num_envs to cmax (the largest shard).  A stream-ordered snapshot in one small launch, so the next
+ * rollout may overwrite the per-env arrays while the collective is still in flight. */
+int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out);
 
 /* ---- state access (also the env checkpoint) ------------------------------------------------ */
 int rmav_get_state(rmav_handle h, float *out, int mem, int layout);      /* nS*N floats */

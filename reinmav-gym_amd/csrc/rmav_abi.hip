@@ -12,7 +12,11 @@
 #include <cstring>
 #include <new>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the RCCL entry points are resolved with dlopen/dlsym on first use
+
 #include "rmav_derive.hpp"
+#include "rmav_gae.hpp"
 #include "rmav_kernels.hpp"
 
 using namespace rmav;
@@ -68,6 +72,18 @@ struct rmav_env_s {
     // scratch for host-pointer calls and layout conversion (grown on demand)
     void *scratch;
     size_t scratch_bytes;
+    // small host-pointer calls (the gym-shaped single env, batch <= a few thousand): one block of pinned,
+    // device-mapped host memory.  The kernel reads the actions from it and writes obs / reward / done into it
+    // over PCIe, so such a call is one launch + one stream synchronise - no staging copies at all.
+    void *pinned;
+    void *pinned_dev;
+    size_t pinned_bytes;
+};
+
+struct rmav_comm_s {
+    uint32_t magic;
+    int rank, world, device;
+    ncclComm_t comm;
 };
 
 namespace {
@@ -129,6 +145,34 @@ int ensure_scratch(rmav_handle h, size_t bytes) {
         return fail(RMAV_ERR_ALLOC, "hipMalloc(%zu) for scratch failed", want);
     }
     h->scratch_bytes = want;
+    return RMAV_OK;
+}
+
+// Host-pointer calls that move at most this many bytes go through the pinned block (zero-copy); bigger ones
+// stage through device scratch with hipMemcpyAsync, which is the faster route for bulk data.
+constexpr size_t kPinnedMax = 256u << 10;
+
+int ensure_pinned(rmav_handle h, size_t bytes) {
+    if (bytes <= h->pinned_bytes) return RMAV_OK;
+    if (h->pinned) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        HIP_TRY(hipHostFree(h->pinned));
+        h->pinned = h->pinned_dev = nullptr;
+        h->pinned_bytes = 0;
+    }
+    size_t want = bytes < 4096 ? 4096 : bytes;
+    if (hipHostMalloc(&h->pinned, want, hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        h->pinned = nullptr;
+        return fail(RMAV_ERR_ALLOC, "hipHostMalloc(%zu) for the pinned staging block failed", want);
+    }
+    if (hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipHostFree(h->pinned);
+        h->pinned = nullptr;
+        return fail(RMAV_ERR_HIP, "hipHostGetDevicePointer failed");
+    }
+    h->pinned_bytes = want;
     return RMAV_OK;
 }
 
@@ -233,11 +277,35 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     case RMAV_ACT_CONTROLLER: return launch_rollout_km<K, ACT_CONTROLLER>(h, a);
     case RMAV_ACT_POLICY: return launch_rollout_km<K, ACT_POLICY>(h, a);
     case RMAV_ACT_POLICY_BF16: return launch_rollout_km<K, ACT_POLICY_BF16>(h, a);
+    case ACT_BUFFER_CTRL: return launch_rollout_kms<K, ACT_BUFFER_CTRL, ST_DEFAULT>(h, a);   // internal (rmav_step_control)
     }
     return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
 
+// n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_STEP_KERNEL=0 falls back to k_rollout)
+template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctrl) {
+    const typename Env<K>::P p = derive_env<K>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params);
+    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
+    else hipLaunchKernelGGL((k_step<K, false>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
 int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
+    static const bool step_kernel = [] {
+        const char *e = getenv("RMAV_STEP_KERNEL");
+        return !(e && atoi(e) == 0);
+    }();
+    if (step_kernel && a.n_steps == 1 && (mode == RMAV_ACT_BUFFER || mode == ACT_BUFFER_CTRL) && h->kind != RMAV_REINMAV) {
+        const bool ctrl = mode == ACT_BUFFER_CTRL;
+        switch (h->kind) {
+        case RMAV_QUAD2D: return launch_step_k<QUAD2D>(h, a, ctrl);
+        case RMAV_QUAD2D_SL: return launch_step_k<QUAD2D_SL>(h, a, ctrl);
+        case RMAV_QUAD3D: return launch_step_k<QUAD3D>(h, a, ctrl);
+        case RMAV_QUAD3D_SL: return launch_step_k<QUAD3D_SL>(h, a, ctrl);
+        }
+    }
     switch (h->kind) {
     case RMAV_QUAD2D: return launch_rollout_k<QUAD2D>(h, mode, a);
     case RMAV_QUAD2D_SL: return launch_rollout_k<QUAD2D_SL>(h, mode, a);
@@ -321,6 +389,11 @@ template <typename T> int copy_out(rmav_handle h, const T *dev, T *out, size_t c
     if (!out) return fail(RMAV_ERR_INVALID, "output pointer is NULL");
     if (mem == RMAV_DEVICE) {
         HIP_TRY(hipMemcpyAsync(out, dev, count * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
+    } else if (count * sizeof(T) <= kPinnedMax && ensure_pinned(h, count * sizeof(T)) == RMAV_OK) {
+        // pinned target: a true asynchronous DMA, then one synchronise (a pageable target makes the runtime stage and block)
+        HIP_TRY(hipMemcpyAsync(h->pinned, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pinned, count * sizeof(T));
     } else {
         HIP_TRY(hipMemcpyAsync(out, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -343,6 +416,7 @@ void free_all(rmav_handle h) {
                     h->totals, h->env_time, h->pe[0], h->pe[1], h->pe[2], h->scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->magic = 0;
     delete h;
@@ -614,14 +688,22 @@ int rmav_reset(rmav_handle h, float *obs_out, int mem, int layout) {
     if (int rc = check_mem_layout(mem, layout)) return rc;
     const size_t nobs = (size_t)h->n * kStateDim[h->kind];
     if (mem == RMAV_DEVICE || !obs_out) return launch_reset(h, obs_out, layout);
+    if (nobs * sizeof(float) <= kPinnedMax && ensure_pinned(h, nobs * sizeof(float)) == RMAV_OK) {   // zero-copy
+        if (int rc = launch_reset(h, (float *)h->pinned_dev, layout)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(obs_out, h->pinned, nobs * sizeof(float));
+        return RMAV_OK;
+    }
     if (int rc = ensure_scratch(h, nobs * sizeof(float))) return rc;
     if (int rc = launch_reset(h, (float *)h->scratch, layout)) return rc;
     return copy_out(h, (const float *)h->scratch, obs_out, nobs, RMAV_HOST);
 }
 
-int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in,
-                 float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
-                 int layout, int fused) {
+// rmav_rollout / rmav_step / rmav_step_control / rmav_control_step.  ctrl_out (nullable): control() of the state the
+// call leaves behind, nA*N floats in `layout` (action_mode must be RMAV_ACT_BUFFER, n_steps 1).
+static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
+                        float *obs_out, float *rew_out, uint8_t *done_out, float *ctrl_out, int mem, int layout,
+                        int fused) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
     if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
@@ -629,36 +711,55 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
         return fail(RMAV_ERR_INVALID, "unknown action_mode %d", action_mode);
     if (action_mode == RMAV_ACT_BUFFER && !actions_in)
         return fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
+    if (ctrl_out && h->kind == RMAV_REINMAV)
+        return fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (RMAV_ACT_CONTROLLER); there is no separate control()");
     const size_t n = (size_t)h->n, T = (size_t)n_steps;
     const size_t nS = kStateDim[h->kind], nA = kActionDim[h->kind];
     const size_t b_act = T * nA * n * sizeof(float), b_obs = T * nS * n * sizeof(float);
-    const size_t b_rew = T * n * sizeof(float), b_done = T * n;
+    const size_t b_rew = T * n * sizeof(float), b_done = T * n, b_ctrl = nA * n * sizeof(float);
+    const bool want_aout = actions_out && action_mode != RMAV_ACT_BUFFER;
 
     const float *d_act_in = actions_in;
-    float *d_act_out = actions_out, *d_obs = obs_out, *d_rew = rew_out;
+    float *d_act_out = actions_out, *d_obs = obs_out, *d_rew = rew_out, *d_ctrl = ctrl_out;
     uint8_t *d_done = done_out;
-    if (mem == RMAV_HOST) {  // stage through device scratch
+    bool pinned = false;
+    char *hbase = nullptr;   // host view of the staging block (pinned path only)
+    size_t o_ain = 0, o_aout = 0, o_obs = 0, o_rew = 0, o_done = 0, o_ctrl = 0;
+    if (mem == RMAV_HOST) {
         auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
-        size_t off = 0, o_ain = 0, o_aout = 0, o_obs = 0, o_rew = 0, o_done = 0;
+        size_t off = 0;
         if (action_mode == RMAV_ACT_BUFFER) { o_ain = off; off += up(b_act); }
-        if (actions_out && action_mode != RMAV_ACT_BUFFER) { o_aout = off; off += up(b_act); }
+        if (want_aout) { o_aout = off; off += up(b_act); }
         if (obs_out) { o_obs = off; off += up(b_obs); }
         if (rew_out) { o_rew = off; off += up(b_rew); }
         if (done_out) { o_done = off; off += up(b_done); }
-        if (int rc = ensure_scratch(h, off ? off : 256)) return rc;
-        char *base = (char *)h->scratch;
-        if (action_mode == RMAV_ACT_BUFFER) {
-            HIP_TRY(hipMemcpyAsync(base + o_ain, actions_in, b_act, hipMemcpyHostToDevice, h->stream));
-            d_act_in = (const float *)(base + o_ain);
+        if (ctrl_out) { o_ctrl = off; off += up(b_ctrl); }
+        if (!off) off = 256;
+        char *base;
+        if (off <= kPinnedMax && ensure_pinned(h, off) == RMAV_OK) {
+            // zero-copy: the kernel reads / writes the pinned host block directly
+            pinned = true;
+            hbase = (char *)h->pinned;
+            base = (char *)h->pinned_dev;
+            if (action_mode == RMAV_ACT_BUFFER) memcpy(hbase + o_ain, actions_in, b_act);
+        } else {   // bulk: stage through device scratch
+            if (int rc = ensure_scratch(h, off)) return rc;
+            base = (char *)h->scratch;
+            if (action_mode == RMAV_ACT_BUFFER)
+                HIP_TRY(hipMemcpyAsync(base + o_ain, actions_in, b_act, hipMemcpyHostToDevice, h->stream));
         }
-        d_act_out = (actions_out && action_mode != RMAV_ACT_BUFFER) ? (float *)(base + o_aout) : nullptr;
+        d_act_in = action_mode == RMAV_ACT_BUFFER ? (const float *)(base + o_ain) : nullptr;
+        d_act_out = want_aout ? (float *)(base + o_aout) : nullptr;
         d_obs = obs_out ? (float *)(base + o_obs) : nullptr;
         d_rew = rew_out ? (float *)(base + o_rew) : nullptr;
         d_done = done_out ? (uint8_t *)(base + o_done) : nullptr;
+        d_ctrl = ctrl_out ? (float *)(base + o_ctrl) : nullptr;
     }
 
     RolloutArgs a = base_args(h);
     if (layout == RMAV_AOS) a.flags |= F_AOS;
+    a.ctrl_out = d_ctrl;
+    const int kmode = d_ctrl ? (int)ACT_BUFFER_CTRL : action_mode;
     if (fused) {
         a.n_steps = n_steps;
         a.act_in = d_act_in;
@@ -666,7 +767,7 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
         a.obs_out = d_obs;
         a.rew_out = d_rew;
         a.done_out = d_done;
-        if (int rc = launch_rollout(h, action_mode, a)) return rc;
+        if (int rc = launch_rollout(h, kmode, a)) return rc;
     } else {
         for (size_t k = 0; k < T; ++k) {
             a.n_steps = 1;
@@ -676,24 +777,54 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
             a.obs_out = d_obs ? d_obs + k * nS * n : nullptr;
             a.rew_out = d_rew ? d_rew + k * n : nullptr;
             a.done_out = d_done ? d_done + k * n : nullptr;
-            if (int rc = launch_rollout(h, action_mode, a)) return rc;
+            if (int rc = launch_rollout(h, (k + 1 == T) ? kmode : action_mode, a)) return rc;
         }
     }
     h->t += T;
 
     if (mem == RMAV_HOST) {
-        if (actions_out && action_mode != RMAV_ACT_BUFFER)
-            HIP_TRY(hipMemcpyAsync(actions_out, d_act_out, b_act, hipMemcpyDeviceToHost, h->stream));
-        if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, b_obs, hipMemcpyDeviceToHost, h->stream));
-        if (rew_out) HIP_TRY(hipMemcpyAsync(rew_out, d_rew, b_rew, hipMemcpyDeviceToHost, h->stream));
-        if (done_out) HIP_TRY(hipMemcpyAsync(done_out, d_done, b_done, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (pinned) {
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (want_aout) memcpy(actions_out, hbase + o_aout, b_act);
+            if (obs_out) memcpy(obs_out, hbase + o_obs, b_obs);
+            if (rew_out) memcpy(rew_out, hbase + o_rew, b_rew);
+            if (done_out) memcpy(done_out, hbase + o_done, b_done);
+            if (ctrl_out) memcpy(ctrl_out, hbase + o_ctrl, b_ctrl);
+        } else {
+            if (want_aout) HIP_TRY(hipMemcpyAsync(actions_out, d_act_out, b_act, hipMemcpyDeviceToHost, h->stream));
+            if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, b_obs, hipMemcpyDeviceToHost, h->stream));
+            if (rew_out) HIP_TRY(hipMemcpyAsync(rew_out, d_rew, b_rew, hipMemcpyDeviceToHost, h->stream));
+            if (done_out) HIP_TRY(hipMemcpyAsync(done_out, d_done, b_done, hipMemcpyDeviceToHost, h->stream));
+            if (ctrl_out) HIP_TRY(hipMemcpyAsync(ctrl_out, d_ctrl, b_ctrl, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+        }
         if (actions_out && action_mode == RMAV_ACT_BUFFER && actions_out != actions_in)
             memcpy(actions_out, actions_in, b_act);
     } else if (actions_out && action_mode == RMAV_ACT_BUFFER && actions_out != actions_in) {
         HIP_TRY(hipMemcpyAsync(actions_out, actions_in, b_act, hipMemcpyDeviceToDevice, h->stream));
     }
     return RMAV_OK;
+}
+
+int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in,
+                 float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
+                 int layout, int fused) {
+    return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, mem,
+                        layout, fused);
+}
+
+int rmav_step_control(rmav_handle h, const float *actions, float *obs_out, float *rew_out, uint8_t *done_out,
+                      float *next_actions_out, int mem, int layout) {
+    if (!actions) return fail(RMAV_ERR_INVALID, "actions is NULL");
+    if (!next_actions_out) return fail(RMAV_ERR_INVALID, "next_actions_out is NULL");
+    return rollout_impl(h, 1, RMAV_ACT_BUFFER, actions, nullptr, obs_out, rew_out, done_out, next_actions_out, mem,
+                        layout, 1);
+}
+
+int rmav_control_step(rmav_handle h, float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
+                      int layout) {
+    return rollout_impl(h, 1, RMAV_ACT_CONTROLLER, nullptr, actions_out, obs_out, rew_out, done_out, nullptr, mem,
+                        layout, 1);
 }
 
 int64_t rmav_policy_weight_count(int kind) {
@@ -747,6 +878,12 @@ int rmav_control(rmav_handle h, float *actions_out, int mem, int layout) {
     if (!actions_out) return fail(RMAV_ERR_INVALID, "actions_out is NULL");
     const size_t nact = (size_t)h->n * kActionDim[h->kind];
     if (mem == RMAV_DEVICE) return launch_control(h, actions_out, layout);
+    if (nact * sizeof(float) <= kPinnedMax && ensure_pinned(h, nact * sizeof(float)) == RMAV_OK) {   // zero-copy
+        if (int rc = launch_control(h, (float *)h->pinned_dev, layout)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(actions_out, h->pinned, nact * sizeof(float));
+        return RMAV_OK;
+    }
     if (int rc = ensure_scratch(h, nact * sizeof(float))) return rc;
     if (int rc = launch_control(h, (float *)h->scratch, layout)) return rc;
     return copy_out(h, (const float *)h->scratch, actions_out, nact, RMAV_HOST);
@@ -876,6 +1013,174 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
     if (cur_return) HIP_TRY(hipMemcpyAsync(cur_return, h->ep_ret, n * sizeof(float), kind, h->stream));
     if (cur_length) HIP_TRY(hipMemcpyAsync(cur_length, h->ep_len, n * sizeof(int32_t), kind, h->stream));
     if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
+    return RMAV_OK;
+}
+
+// ---- learner-side helpers on the trajectory ----------------------------------------------------
+int rmav_gae(rmav_handle h, int32_t n_steps, const float *rew, const uint8_t *done, const float *values,
+             float gamma, float lam, float reward_scale, float *adv_out, float *ret_out, double *sums_out) {
+    CHECK_HANDLE(h);
+    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (!rew || !done || !values || !adv_out || !ret_out)
+        return fail(RMAV_ERR_INVALID, "rew, done, values, adv_out and ret_out are required (device pointers)");
+    const unsigned nblk = (unsigned)((h->n + 255) / 256);
+    double *partial = nullptr;
+    if (sums_out) {
+        if (int rc = ensure_scratch(h, (size_t)nblk * 2 * sizeof(double))) return rc;
+        partial = (double *)h->scratch;
+    }
+    hipLaunchKernelGGL(k_gae, dim3(nblk), dim3(256), 0, h->stream, rew, done, values, adv_out, ret_out, h->n, n_steps,
+                       gamma, lam, reward_scale, partial);
+    HIP_TRY(hipGetLastError());
+    if (sums_out) {
+        hipLaunchKernelGGL(k_gae_fold, dim3(1), dim3(256), 0, h->stream, (const double *)partial, (int)nblk, sums_out);
+        HIP_TRY(hipGetLastError());
+    }
+    return RMAV_OK;
+}
+
+int rmav_normalize(rmav_handle h, float *x, int64_t count, float mean, float rstd) {
+    CHECK_HANDLE(h);
+    if (!x || count < 0) return fail(RMAV_ERR_INVALID, "x is NULL or count < 0");
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return fail(RMAV_ERR_INVALID, "x must be 16-byte aligned");
+    if (count == 0) return RMAV_OK;
+    int64_t blocks = (count / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;   // grid-stride: 16 blocks per CU keep the memory system full
+    hipLaunchKernelGGL(k_affine, dim3((unsigned)blocks), dim3(256), 0, h->stream, x, count, mean, rstd);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+// ---- the path's one collective, behind the C ABI: RCCL all-gather of per-env episode statistics ---------------
+namespace {
+struct RcclApi {
+    void *lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+// resolved on first use: librmav.so has no link-time dependency on RCCL, and a process that already loaded
+// librccl.so.1 (torch does) shares that copy
+RcclApi *rccl() {
+    static RcclApi api;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (api.lib) break;
+        }
+        if (api.lib) {
+            api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+            api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+            api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+            api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
+            api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+            if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.lib = nullptr;
+        }
+    }
+    return api.lib ? &api : nullptr;
+}
+constexpr uint32_t kCommMagic = 0x524d4143u;  // 'RMAC'
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        ncclResult_t r_ = (expr);                                                                  \
+        if (r_ != ncclSuccess)                                                                     \
+            return fail(RMAV_ERR_HIP, "%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+}  // namespace
+
+int rmav_comm_unique_id(void *id_out) {
+    if (!id_out) return fail(RMAV_ERR_INVALID, "id_out is NULL");
+    RcclApi *R = rccl();
+    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    ncclUniqueId id;
+    RCCL_TRY(R->GetUniqueId(&id));
+    static_assert(sizeof(id) == RMAV_COMM_ID_BYTES, "RCCL unique id size");
+    memcpy(id_out, &id, sizeof(id));
+    return RMAV_OK;
+}
+
+int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device) {
+    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!id || world <= 0 || rank < 0 || rank >= world) return fail(RMAV_ERR_INVALID, "need id and 0 <= rank < world");
+    const int ndev = rmav_device_count();
+    if (ndev <= 0) return fail(RMAV_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    RcclApi *R = rccl();
+    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    DeviceGuard guard(device);
+    if (!guard.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    rmav_comm c = new (std::nothrow) rmav_comm_s();
+    if (!c) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    c->magic = kCommMagic;
+    c->rank = rank;
+    c->world = world;
+    c->device = device;
+    c->comm = nullptr;
+    ncclResult_t r = R->CommInitRank(&c->comm, world, uid, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(RMAV_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+    }
+    *out = c;
+    return RMAV_OK;
+}
+
+int rmav_comm_destroy(rmav_comm c) {
+    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    RcclApi *R = rccl();
+    if (R && c->comm) (void)R->CommDestroy(c->comm);
+    c->magic = 0;
+    delete c;
+    return RMAV_OK;
+}
+
+int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
+    CHECK_HANDLE(h);
+    if (!(h->flags & RMAV_F_TRACK_EPISODES))
+        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    if (!send_out || cmax < h->n) return fail(RMAV_ERR_INVALID, "send_out is NULL or cmax < num_envs");
+    hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, send_out);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out) {
+    CHECK_HANDLE(h);
+    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (!(h->flags & RMAV_F_TRACK_EPISODES))
+        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
+    if (c->device != h->device) return fail(RMAV_ERR_INVALID, "communicator and handle live on different devices");
+    const int64_t W = c->world, base = n_total / W, rem = n_total % W;
+    if (n_total <= 0 || base == 0) return fail(RMAV_ERR_INVALID, "n_total must be >= the number of ranks");
+    const int64_t count = base + (c->rank < rem ? 1 : 0), start = c->rank * base + (c->rank < rem ? c->rank : rem);
+    if (h->n != count || (int64_t)h->env_base != start)
+        return fail(RMAV_ERR_INVALID, "rank %d of %d must own envs [%lld, %lld) of %lld; the handle owns [%llu, %llu)", c->rank,
+                    c->world, (long long)start, (long long)(start + count), (long long)n_total,
+                    (unsigned long long)h->env_base, (unsigned long long)(h->env_base + (uint64_t)h->n));
+    RcclApi *R = rccl();
+    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    const int64_t cmax = base + (rem ? 1 : 0);
+    const size_t send_b = (size_t)(2 * cmax) * sizeof(int32_t), recv_b = send_b * (size_t)W;
+    if (int rc = ensure_scratch(h, send_b + recv_b + 256)) return rc;
+    int32_t *send = (int32_t *)h->scratch;
+    int32_t *recv = (int32_t *)((char *)h->scratch + ((send_b + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
+                       (const float *)h->last_ret, (const int32_t *)h->last_len, count, cmax, send);
+    HIP_TRY(hipGetLastError());
+    RCCL_TRY(R->AllGather(send, recv, (size_t)(2 * cmax), ncclInt32, c->comm, h->stream));
+    hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
+                       (const int32_t *)recv, n_total, (int32_t)W, cmax, returns_out, lengths_out);
+    HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
 

@@ -1,0 +1,164 @@
+// rmav_gae.hpp - generalised advantage estimation over the time-major [T][N] trajectory a fused rollout leaves
+// in HBM (the PPO2 caller loop of gym_reinmav/run.py:63-68; baselines ppo2 Runner.run() computes
+//   delta_t = r_t + gamma V_{t+1} (1 - done_t) - V_t ,   A_t = delta_t + gamma lambda (1 - done_t) A_{t+1}
+// backwards over the nsteps it collected, returns = A + V).
+//
+// One env per lane, like the dynamics kernels: lane i walks its own column backwards, so every access of a
+// time step is one coalesced 256-byte (64-byte for `done`) wave transaction and the recurrence lives in two
+// registers.  9 bytes read + 8 written per sample: a pure HBM stream.  The loads of a chunk of kGaeUnroll
+// steps do not depend on the recurrence, so they are all issued before the first one is consumed.
+// The kernel also leaves sum / sum-of-squares of the advantages (per-block partials in fp64, folded by
+// k_gae_fold) for the advantage normalisation of the learner.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace rmav {
+
+constexpr int kGaeUnroll = 8;
+
+__global__ __launch_bounds__(256) void k_gae(const float *__restrict__ rew, const uint8_t *__restrict__ done,
+                                             const float *__restrict__ val, float *__restrict__ adv,
+                                             float *__restrict__ ret, int64_t n, int32_t T, float gamma, float lam,
+                                             float rew_scale, double *__restrict__ partial) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float s1 = 0.0f, s2 = 0.0f;
+    if (i < n) {
+        float v_next = val[(int64_t)T * n + i];
+        float last = 0.0f;
+        const float gl = gamma * lam;
+        int32_t t = T - 1;
+        // head: bring t + 1 to a multiple of the unroll factor
+        for (; t >= 0 && ((t + 1) % kGaeUnroll) != 0; --t) {
+            const int64_t o = (int64_t)t * n + i;
+            const float nt = done[o] ? 0.0f : 1.0f, v = val[o];
+            const float delta = fmaf(gamma * nt, v_next, fmaf(rew[o], rew_scale, -v));
+            last = fmaf(gl * nt, last, delta);
+            adv[o] = last;
+            ret[o] = last + v;
+            s1 += last;
+            s2 = fmaf(last, last, s2);
+            v_next = v;
+        }
+        for (; t >= 0; t -= kGaeUnroll) {
+            float r[kGaeUnroll], v[kGaeUnroll], nt[kGaeUnroll];
+#pragma unroll
+            for (int j = 0; j < kGaeUnroll; ++j) {
+                const int64_t o = (int64_t)(t - j) * n + i;
+                r[j] = rew[o];
+                v[j] = val[o];
+                nt[j] = done[o] ? 0.0f : 1.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < kGaeUnroll; ++j) {
+                const int64_t o = (int64_t)(t - j) * n + i;
+                const float delta = fmaf(gamma * nt[j], v_next, fmaf(r[j], rew_scale, -v[j]));
+                last = fmaf(gl * nt[j], last, delta);
+                adv[o] = last;
+                ret[o] = last + v[j];
+                s1 += last;
+                s2 = fmaf(last, last, s2);
+                v_next = v[j];
+            }
+        }
+    }
+    if (partial) {   // block partial of (sum A, sum A^2); uniform branch
+        __shared__ double sh[2][4];
+        double d1 = (double)s1, d2 = (double)s2;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            d1 += __shfl_down(d1, off, 64);
+            d2 += __shfl_down(d2, off, 64);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            sh[0][w] = d1;
+            sh[1][w] = d2;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+                a1 += sh[0][k];
+                a2 += sh[1][k];
+            }
+            partial[2 * blockIdx.x] = a1;
+            partial[2 * blockIdx.x + 1] = a2;
+        }
+    }
+}
+
+// one block: sums_out[0..1] = (sum A, sum A^2) over all blocks' partials
+__global__ __launch_bounds__(256) void k_gae_fold(const double *__restrict__ partial, int nblocks, double *__restrict__ sums_out) {
+    double a1 = 0.0, a2 = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        a1 += partial[2 * b];
+        a2 += partial[2 * b + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        a1 += __shfl_down(a1, off, 64);
+        a2 += __shfl_down(a2, off, 64);
+    }
+    __shared__ double sh[2][4];
+    if ((threadIdx.x & 63) == 0) {
+        sh[0][threadIdx.x >> 6] = a1;
+        sh[1][threadIdx.x >> 6] = a2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums_out[0] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        sums_out[1] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    }
+}
+
+// x <- (x - mean) * rstd, 16 bytes per lane, grid-stride; count4 = count / 4 full quads, the tail by scalar lanes
+__global__ __launch_bounds__(256) void k_affine(float *__restrict__ x, int64_t count, float mean, float rstd) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n4 = count >> 2;
+    float4 *x4 = reinterpret_cast<float4 *>(x);
+    for (int64_t q = tid; q < n4; q += stride) {
+        float4 v = x4[q];
+        v.x = (v.x - mean) * rstd;
+        v.y = (v.y - mean) * rstd;
+        v.z = (v.z - mean) * rstd;
+        v.w = (v.w - mean) * rstd;
+        x4[q] = v;
+    }
+    for (int64_t q = (n4 << 2) + tid; q < count; q += stride) x[q] = (x[q] - mean) * rstd;
+}
+
+// ---- episode statistics exchange (the path's one collective) ------------------------------------------------
+// send = [2][cmax] int32: returns (bit pattern) then lengths of this rank's `count` envs, zero padded to cmax
+__global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ last_ret, const int32_t *__restrict__ last_len,
+                                                    int64_t count, int64_t cmax, int32_t *__restrict__ send) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cmax) return;
+    send[i] = i < count ? __float_as_int(last_ret[i]) : 0;
+    send[cmax + i] = i < count ? last_len[i] : 0;
+}
+// recv = [world][2][cmax] -> returns_out / lengths_out [n_total] in global env order (rank r owns
+// base + (r < rem) envs starting at r * base + min(r, rem))
+__global__ __launch_bounds__(256) void k_unpack_stats(const int32_t *__restrict__ recv, int64_t n_total, int32_t world,
+                                                      int64_t cmax, float *__restrict__ ret_out, int32_t *__restrict__ len_out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_total) return;
+    const int64_t base = n_total / world, rem = n_total % world;
+    // owner of global env g: the first `rem` ranks hold base + 1 envs
+    const int64_t cut = rem * (base + 1);
+    int64_t r, local;
+    if (g < cut) {
+        r = g / (base + 1);
+        local = g - r * (base + 1);
+    } else {
+        r = rem + (g - cut) / base;
+        local = (g - cut) - (r - rem) * base;
+    }
+    const int32_t *src = recv + r * 2 * cmax;
+    ret_out[g] = __int_as_float(src[local]);
+    len_out[g] = src[cmax + local];
+}
+
+}  // namespace rmav

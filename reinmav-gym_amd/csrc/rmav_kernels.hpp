@@ -32,8 +32,12 @@ namespace rmav {
 
 enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3, ACT_POLICY_BF16 = 4,
               // internal: ACT_RANDOM / ACT_CONTROLLER with a second, "memory" wavefront per 64 envs (see k_rollout)
-              ACT_RANDOM_SPLIT = 5, ACT_CONTROLLER_SPLIT = 6 };
+              ACT_RANDOM_SPLIT = 5, ACT_CONTROLLER_SPLIT = 6,
+              // internal: ACT_BUFFER, and the launch ends by evaluating control() on the state it leaves behind
+              // (rmav_step_control: the gym-shaped single env gets step()'s outputs and the NEXT control() in one launch)
+              ACT_BUFFER_CTRL = 7 };
 constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT; }
+constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
 // Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
 // (actions: helper -> integrator, only when the helper draws them; obs + reward + done [+ actions]: integrator -> helper)
 #ifndef RMAV_SPLIT_CHUNK
@@ -86,6 +90,7 @@ struct RolloutArgs {
     const float *policy_w;  // packed weights (rmav_policy.hpp layout), device memory
     float *logp_out;        // [n_steps][N]
     float *val_out;         // [n_steps + 1][N]
+    float *ctrl_out;        // ACT_BUFFER_CTRL only: control() of the state after the last step, [nA][N] | [N][nA]
 };
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
@@ -169,6 +174,9 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     const bool aos = (a.flags & F_AOS) != 0;
     const bool track = (a.flags & F_TRACK) != 0;
     const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
+
+    // (the hosts rejects n_steps <= 0; the two-wavefront barrier protocol below needs at least one step)
+    if (a.n_steps <= 0) return;
 
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
@@ -269,7 +277,10 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 #pragma unroll
                                 for (int q = 0; q < NS; ++q) o[q] = tile[aos_rd[q]];
 #pragma unroll
-                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, lane * 4u, 256u * q, o[q]);
+                                // the per-q term rides in the instruction's immediate offset (256 q <= 3840 < 4096), which the
+                                // range check covers; an SGPR soffset is NOT range-checked and would let the clone rows
+                                // of a ragged last wavefront land past this wavefront's valid rows
+                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, lane * 4u + 256u * q, 0u, o[q]);
                             } else {
                                 const rsrc_t ro = make_rsrc(dst_step);
 #pragma unroll
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
 
         // uniform cursors into the time-major trajectory buffers, advanced once per step
         const float *act_in = a.act_in;
-        float *act_out = (MODE != ACT_BUFFER && !SPLIT) ? a.act_out : nullptr;   // SPLIT: the memory wavefront writes them
+        float *act_out = (!is_buffer(MODE) && !SPLIT) ? a.act_out : nullptr;   // SPLIT: the memory wavefront writes them
         float *obs_out = a.obs_out;
         float *rew_out = a.rew_out;
         uint8_t *done_out = a.done_out;
@@ -420,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 for (int c = 0; c < NA; ++c) dst[c] = buf_ld(r, off, (uint32_t)c * col);
             }
         };
-        if constexpr (MODE == ACT_BUFFER) load_actions(act_in, act_pre);
+        if constexpr (is_buffer(MODE)) load_actions(act_in, act_pre);
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
@@ -461,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 buf_st(make_rsrc(val_out), off, 0, val[0]);
                 logp_out += n;
                 val_out += n;
-            } else if constexpr (MODE == ACT_BUFFER) {
+            } else if constexpr (is_buffer(MODE)) {
                 // the action of step k was fetched while step k-1 was integrated (see the prefetch below): with one
                 // wavefront per SIMD an action load issued at the top of its own step exposes a full memory
                 // round trip per step (1.40 -> 1.26 us per env-step batch at 65 536 envs)
@@ -628,6 +639,19 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
         }
 #pragma unroll
         for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+        if constexpr (MODE == ACT_BUFFER_CTRL && K != REINMAV) {   // control() of the state this launch leaves behind
+            float a2[NA];
+            env_control<K>(s, pc, a2);
+            if (aos) {
+                float *dst = a.ctrl_out + (int64_t)li * NA;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) dst[c] = a2[c];
+            } else {
+                const rsrc_t rc2 = make_rsrc(a.ctrl_out);
+#pragma unroll
+                for (int c = 0; c < NA; ++c) buf_st(rc2, off, (uint32_t)c * col, a2[c]);
+            }
+        }
         if (track) {
             buf_st(make_rsrc(a.ep_ret), off, 0, er);
             buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
@@ -661,6 +685,156 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 atomicAdd(&slot->episodes, (unsigned long long)wn);
                 atomicAdd(&slot->length_sum, (unsigned long long)wl);
                 atomicAdd(&slot->return_sum, (double)wr);
+            }
+        }
+    }
+}
+
+// One env-step per launch (rmav_step, rmav_step_control, the fused = 0 loop of rmav_rollout with caller actions).
+// At BASELINE's 65 536 envs such a launch is latency-bound (a few us against 0.8 us of HBM time), so this is
+// k_rollout<K, ACT_BUFFER> at n_steps = 1 re-cut for latency, same arithmetic and same bits:
+//   * a small straight-line body (no step loop, action prefetch, spare reset state, store-policy or tile variants):
+//     less code to fetch into an instruction cache that is cold at every kernel boundary;
+//   * outputs that do not depend on the reset state (reward, done, episode accumulators, last-episode stores,
+//     steps_beyond_done) are issued BEFORE the Philox draws of reset_state(), whose ~130 instructions then run
+//     under the stores' flight time; only the state / obs stores wait for them;
+//   * no atomics: the wavefront's slot of the episode totals is read with scalar loads at the top of the kernel
+//     (in flight beside the state loads) and rewritten by one lane with plain stores; the per-wave sums are
+//     gathered with v_readlane over the set bits of the `done` ballot (usually one bit) instead of shuffle
+//     reductions.  (k_rollout adds to the same slots with atomics; launches are stream-ordered, so they mix.)
+template <int K, bool CTRL>
+__global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const typename Env<K>::P p_shared,
+                                                 const ParamsT<double> pc_shared) {
+    static_assert(K != REINMAV, "ReinmavEnv steps go through k_rollout");
+    constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
+    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = a.n;
+    const bool valid = gi < (uint64_t)n;
+    const uint32_t li = gi;
+    const uint32_t col = (uint32_t)n * 4u, off = li * 4u;
+    const bool aos = (a.flags & F_AOS) != 0;
+    const bool track = (a.flags & F_TRACK) != 0;
+    const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
+
+    // this wavefront's totals slot, through the scalar cache (wave-uniform address)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(gi >> 6);
+    Totals tot = {0ull, 0.0, 0ull};
+    if (track) tot = a.totals[wave];
+
+    bool fin = false;
+    float fin_ret = 0.0f;
+    int32_t fin_len = 0;
+    if (valid) {
+        const rsrc_t r_state = make_rsrc(a.state);
+        float s[NS], act[NA];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
+        if (aos) {
+            const float *src = a.act_in + (int64_t)li * NA;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) act[c] = src[c];
+        } else {
+            const rsrc_t r = make_rsrc(a.act_in);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * col);
+        }
+        float er = 0.0f;
+        int32_t el = 0;
+        if (track) {
+            er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+            el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+        }
+        int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+        uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+        const uint64_t env_id = a.env_base + (uint64_t)li;
+        typename Env<K>::P pl = p_shared;
+        ParamsT<double> pcl = pc_shared;
+        if (a.pe[0] || a.pe[1] || a.pe[2]) {
+            const double m = a.pe[0] ? (double)a.pe[0][li] : (double)pc_shared.mass;
+            const double ml = a.pe[1] ? (double)a.pe[1][li] : (double)pc_shared.load_mass;
+            const double L = a.pe[2] ? (double)a.pe[2][li] : (double)pc_shared.L;
+            override_params(pl, m, ml, L);
+            override_params(pcl, m, ml, L);
+        }
+
+        float dist = 0.0f;
+        bool done;
+        Env<K>::step(s, act, pl, dist, done);
+        // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
+        float r = -dist;
+        if (done) {
+            r = (sb < 0) ? 1.0f : 0.0f;
+            sb = (sb < 0) ? 0 : sb + 1;
+        }
+        // everything that does not need the reset state goes out first
+        if (a.rew_out) buf_st(make_rsrc(a.rew_out), off, 0, r);
+        if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, 0);
+        if (track) {
+            er += r;
+            el += 1;
+            if (done) {
+                buf_st(make_rsrc(a.last_ret), off, 0, er);
+                buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                fin = true;
+                fin_ret = er;
+                fin_len = el;
+                er = 0.0f;
+                el = 0;
+            }
+            buf_st(make_rsrc(a.ep_ret), off, 0, er);
+            buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+        }
+        if (done) {
+            buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
+            if (auto_reset) {
+                buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)(rc + 1u));
+                reset_state<K>(a.seed, env_id, rc, s);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+        if (a.obs_out) {
+            if (aos) {
+                float *dst = a.obs_out + (int64_t)li * NS;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) dst[c] = s[c];
+            } else {
+                const rsrc_t ro = make_rsrc(a.obs_out);
+#pragma unroll
+                for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
+            }
+        }
+        if constexpr (CTRL) {   // control() of the state this launch leaves behind
+            float a2[NA];
+            env_control<K>(s, pcl, a2);
+            if (aos) {
+                float *dst = a.ctrl_out + (int64_t)li * NA;
+#pragma unroll
+                for (int c = 0; c < NA; ++c) dst[c] = a2[c];
+            } else {
+                const rsrc_t rc2 = make_rsrc(a.ctrl_out);
+#pragma unroll
+                for (int c = 0; c < NA; ++c) buf_st(rc2, off, (uint32_t)c * col, a2[c]);
+            }
+        }
+    }
+    if (track) {
+        uint64_t m = __ballot(fin);
+        if (m != 0) {   // wave-uniform
+            uint32_t cnt = 0, len = 0;
+            float ret = 0.0f;
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                cnt += 1u;
+                len += (uint32_t)__builtin_amdgcn_readlane(fin_len, l);
+                ret += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fin_ret), l));
+            }
+            if ((threadIdx.x & 63u) == 0u) {
+                Totals *slot = a.totals + wave;
+                slot->episodes = tot.episodes + cnt;
+                slot->return_sum = tot.return_sum + (double)ret;
+                slot->length_sum = tot.length_sum + len;
             }
         }
     }

@@ -25,6 +25,7 @@ POLICY_FP32, POLICY_BF16_MFMA = 0, 1
 INT_EULER, INT_RK4 = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
+COMM_ID_BYTES = 128
 
 
 class RmavError(RuntimeError):
@@ -84,11 +85,20 @@ PROTOTYPES = {
     "rmav_reset": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _u8p, C.c_int, C.c_int]),
     "rmav_control": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
+    "rmav_control_step": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _u8p, C.c_int, C.c_int]),
+    "rmav_step_control": (C.c_int, [C.c_void_p, _fp, _fp, _fp, _u8p, _fp, C.c_int, C.c_int]),
     "rmav_rollout": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int, C.c_int,
                                C.c_int]),
     "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
     "rmav_policy_weight_count_bf16": (C.c_int64, []),
     "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp, C.c_int]),
+    "rmav_gae": (C.c_int, [C.c_void_p, C.c_int32, _fp, _u8p, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _vp]),
+    "rmav_normalize": (C.c_int, [C.c_void_p, _fp, C.c_int64, C.c_float, C.c_float]),
+    "rmav_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "rmav_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "rmav_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rmav_allgather_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
+    "rmav_pack_stats": (C.c_int, [C.c_void_p, C.c_int64, _vp]),
     "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_set_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_get_sbd": (C.c_int, [C.c_void_p, _vp, C.c_int]),

@@ -173,6 +173,58 @@ class BatchedQuadrotor:
         A.check(self._lib.rmav_control(self._h, self._ptr(act), A.DEVICE if device_out else A.HOST, _layout(layout)))
         return act
 
+    def control_step(self, layout: str = "aos", out=None, device_out: bool = False):
+        """``a = control(); step(a)`` in one launch -> (actions, obs, reward, done)."""
+        dev = device_out or (out is not None and _is_tensor(out[0]))
+        if out is None:
+            act = self._new(self._shape(self.nA, layout), np.float32, dev)
+            obs = self._new(self._shape(self.nS, layout), np.float32, dev)
+            rew = self._new((self.num_envs,), np.float32, dev)
+            done = self._new((self.num_envs,), np.uint8, dev)
+        else:
+            act, obs, rew, done = out
+        A.check(self._lib.rmav_control_step(self._h, self._ptr(act), self._ptr(obs), self._ptr(rew), self._ptr(done),
+                                            A.DEVICE if dev else A.HOST, _layout(layout)))
+        if not dev and out is None:
+            done = done.astype(bool)
+        return act, obs, rew, done
+
+    def step_control(self, actions, layout: str = "aos", out=None):
+        """``step(actions)`` and, in the same launch, ``control()`` of the new state
+        -> (obs, reward, done, next_actions)."""
+        a, mem = self._in(actions, self._shape(self.nA, layout))
+        dev = mem == A.DEVICE
+        if out is None:
+            obs = self._new(self._shape(self.nS, layout), np.float32, dev)
+            rew = self._new((self.num_envs,), np.float32, dev)
+            done = self._new((self.num_envs,), np.uint8, dev)
+            nxt = self._new(self._shape(self.nA, layout), np.float32, dev)
+        else:
+            obs, rew, done, nxt = out
+        A.check(self._lib.rmav_step_control(self._h, self._ptr(a), self._ptr(obs), self._ptr(rew), self._ptr(done),
+                                            self._ptr(nxt), mem, _layout(layout)))
+        if not dev and out is None:
+            done = done.astype(bool)
+        return obs, rew, done, nxt
+
+    def gae(self, rew, done, values, gamma: float = 0.99, lam: float = 0.95, reward_scale: float = 1.0, out=None,
+            sums=None):
+        """GAE(lambda) over a time-major device trajectory (``rmav_gae``): rew f32 [T,N], done u8 [T,N],
+        values f32 [T+1,N] -> (adv [T,N], returns [T,N]); ``sums`` (f64[2] device tensor, optional) receives
+        (sum A, sum A^2)."""
+        T = int(rew.shape[0])
+        assert tuple(rew.shape) == (T, self.num_envs) and tuple(done.shape) == (T, self.num_envs)
+        assert tuple(values.shape) == (T + 1, self.num_envs) and done.dtype == torch.uint8
+        adv, ret = out if out is not None else (torch.empty_like(rew), torch.empty_like(rew))
+        A.check(self._lib.rmav_gae(self._h, T, self._ptr(rew), self._ptr(done), self._ptr(values), float(gamma), float(lam),
+                                   float(reward_scale), self._ptr(adv), self._ptr(ret), self._ptr(sums)))
+        return adv, ret
+
+    def normalize_(self, x, mean: float, rstd: float):
+        """In place ``x <- (x - mean) * rstd`` on the env's stream (advantage normalisation)."""
+        A.check(self._lib.rmav_normalize(self._h, self._ptr(x), x.numel(), float(mean), float(rstd)))
+        return x
+
     def rollout(self, n_steps: int, mode: str = "random", actions=None, layout: str = "soa", fused: bool = True,
                 want=("obs", "rew", "done"), device_out: bool = False, out: Optional[dict] = None) -> dict:
         """Run ``n_steps`` steps of every env.  Returns a dict of the requested trajectories
@@ -254,6 +306,12 @@ class BatchedQuadrotor:
         t = A.EpTotals()
         A.check(self._lib.rmav_episode_totals(self._h, C.byref(t), 1 if clear else 0))
         return {"episodes": int(t.episodes), "return_sum": float(t.return_sum), "length_sum": int(t.length_sum)}
+
+    def pack_stats(self, send):
+        """send i32[2 * cmax] (device tensor) <- (last returns as bits | last lengths), zero padded: the payload of
+        the per-rollout all-gather, written by one small launch on the env's stream."""
+        A.check(self._lib.rmav_pack_stats(self._h, send.numel() // 2, self._ptr(send)))
+        return send
 
     def episode_buffers(self, device_out: bool = False) -> dict:
         n = (self.num_envs,)

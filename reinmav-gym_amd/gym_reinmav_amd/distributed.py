@@ -68,6 +68,72 @@ def all_gather_episode_stats(last_return, last_length, n_total: int, group=None)
     return torch.cat(rets), torch.cat(lens)
 
 
+class EpisodeStatsExchange:
+    """The per-rollout all-gather, overlapped with the next rollout.
+
+    ``post(env)`` packs this rank's (last_return, last_length) into one of two send buffers on the env's
+    stream (a stream-ordered snapshot: the next rollout may overwrite the per-env arrays at once) and issues
+    the RCCL all-gather on a second stream that waits only for that pack; ``result()`` makes the current
+    stream wait for the most recent gather and returns (returns f32[n_total], lengths i32[n_total]) in global
+    env order.  Equal-sized shards take the zero-slicing path; ragged ones pad to the largest shard."""
+
+    def __init__(self, n_total: int, device, group=None):
+        self.n_total, self.group = int(n_total), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        _, self.count = shard_range(self.n_total, self.rank, self.world)
+        self.cmax = -(-self.n_total // self.world)
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
+        self.send = [torch.zeros(2 * self.cmax, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.recv = [torch.empty(self.world * 2 * self.cmax, dtype=torch.int32, device=self.device) for _ in range(2)]
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        self.done_ev = [None, None]
+        self.i = 0
+        self.last = None
+
+    def post(self, last_return=None, last_length=None, env=None):
+        """Either the two per-env tensors, or ``env=`` a BatchedQuadrotor shard (packed by one launch of its own)."""
+        k = self.i & 1
+        self.i += 1
+        cur = torch.cuda.current_stream(self.device) if self.on_gpu else None
+        if self.on_gpu and self.done_ev[k] is not None:
+            cur.wait_event(self.done_ev[k])               # the gather that last used this pair of buffers
+        s = self.send[k]
+        if env is not None:
+            assert env.num_envs == self.count
+            env.pack_stats(s)
+        else:
+            s[:self.count].copy_(last_return.view(torch.int32))
+            s[self.cmax:self.cmax + self.count].copy_(last_length)
+        if self.on_gpu:
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                dist.all_gather_into_tensor(self.recv[k], s, group=self.group)
+                ev = torch.cuda.Event()
+                ev.record(self.comm_stream)
+            self.done_ev[k] = ev
+        else:
+            dist.all_gather_into_tensor(self.recv[k], s, group=self.group)
+        self.last = k
+
+    def result(self):
+        assert self.last is not None, "post() first"
+        k = self.last
+        if self.on_gpu:
+            torch.cuda.current_stream(self.device).wait_event(self.done_ev[k])
+        recv = self.recv[k].view(self.world, 2, self.cmax)
+        if self.n_total % self.world == 0:
+            return recv[:, 0, :].reshape(-1).view(torch.float32), recv[:, 1, :].reshape(-1)
+        rets, lens = [], []
+        for r in range(self.world):
+            _, c = shard_range(self.n_total, r, self.world)
+            rets.append(recv[r, 0, :c].view(torch.float32))
+            lens.append(recv[r, 1, :c])
+        return torch.cat(rets), torch.cat(lens)
+
+
 def all_reduce_totals(totals: dict, device=None, group=None) -> dict:
     """Sum {'episodes','return_sum','length_sum'} over ranks (one 3-element all-reduce)."""
     t = torch.tensor([float(totals["episodes"]), float(totals["return_sum"]), float(totals["length_sum"])],

@@ -103,12 +103,22 @@ class RolloutCollector:
         env = self.env
         side = torch.cuda.Stream(device=env.device)
         side.wait_stream(torch.cuda.current_stream(env.device))
-        state = env.get_state(layout="soa", device_out=True)  # warm-up must not advance the envs for the caller
-        sbd, rc = env.get_sbd(), env.get_reset_counts()
+        state = env.get_state(layout="soa", device_out=True)
+        t0 = env.step_count
         with torch.cuda.stream(side):
-            env.use_stream(side)
-            self._body()                                        # warm-up (allocator, lazy inits)
+            # warm-up (allocator, lazy inits of the torch ops) on a scratch env of the same shape, so that the
+            # caller's envs - state, steps_beyond_done, reset counters, episode accumulators and totals, clocks -
+            # are not advanced by it; the capture below records launches on the real env without executing them
+            tmp = BatchedQuadrotor(env.kind, env.num_envs, device=env.device, seed=0, auto_reset=True,
+                                   track_episodes=env.track_episodes, params=env.params)
+            self.env = tmp
+            try:
+                self._body()
+            finally:
+                self.env = env
             side.synchronize()
+            tmp.close()
+            env.use_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
                 self._body()
@@ -116,15 +126,14 @@ class RolloutCollector:
         cur = torch.cuda.current_stream(env.device)
         cur.wait_stream(side)
         env.use_stream(cur)                                     # replays run on the caller's current stream
-        env.set_state(state, layout="soa")                      # restore: capture itself does not execute,
-        env.set_sbd(sbd)                                        # but the warm-up did
-        env.set_reset_counts(rc)
+        env.step_count = t0                                     # host-side counter advanced while capturing
         self.obs[0].copy_(state)
 
     def collect(self):
         """Run one rollout; buffers are valid after the current stream's work completes."""
         if self._graph is not None:
             self._graph.replay()
+            self.env.step_count = self.env.step_count + self.T   # the captured launches carry no host-side effects
         else:
             self._body()
         return self
@@ -276,7 +285,9 @@ class FusedPolicyCollector:
 
 
 def gae(rew, val, done, gamma: float = 0.99, lam: float = 0.95):
-    """Generalised advantage estimation on time-major device tensors.
+    """Generalised advantage estimation on time-major tensors - the plain torch fp32 form (T small launches per
+    call), kept as the reference the HIP kernel (``BatchedQuadrotor.gae`` -> ``rmav_gae``) is tested against and
+    for CPU tensors; ``PPO.update`` uses the kernel.
 
     rew [T,N], val [T+1,N] (val[T] = bootstrap value), done [T,N] (1 = the episode ended with step t; the
     next obs is a fresh reset and must not be bootstrapped from).  Returns (adv [T,N], returns [T,N])."""
@@ -319,8 +330,11 @@ class PPO:
 
     def update(self, ro: RolloutCollector) -> dict:
         T, N = ro.rew.shape
-        rew = ro.rew if self.reward_scale == 1.0 else ro.rew * self.reward_scale
-        adv, ret = gae(rew, ro.val, ro.done, self.gamma, self.lam)
+        if ro.rew.is_cuda:   # one HIP launch over the [T][N] trajectory (per-lane reverse scan, csrc/rmav_gae.hpp)
+            adv, ret = ro.env.gae(ro.rew, ro.done, ro.val, self.gamma, self.lam, self.reward_scale)
+        else:
+            rew = ro.rew if self.reward_scale == 1.0 else ro.rew * self.reward_scale
+            adv, ret = gae(rew, ro.val, ro.done, self.gamma, self.lam)
         obs = ro.obs[:T].permute(1, 0, 2).reshape(ro.obs.shape[1], T * N)   # [nS, T*N] feature-major
         act = ro.act.permute(1, 0, 2).reshape(ro.act.shape[1], T * N)
         logp_old, val_old = ro.logp.reshape(-1), ro.val[:T].reshape(-1)

@@ -26,7 +26,7 @@ _ACTION_BOX = {"reinmav": (0.0, 3.5316), "quad2d": (-10.0, 10.0), "quad2d_sl": (
 
 class QuadrotorVecEnv:
     def __init__(self, env_id: str, num_envs: int, device: int = 0, seed: int = 0, env_id_base: int = 0,
-                 numpy_io: bool = False, dict_infos=None, reading_2d=None):
+                 numpy_io: bool = False, dict_infos=None, reading_2d=None, reuse_buffers: bool = False):
         kind = ENV_IDS.get(env_id, env_id)
         self.env = BatchedQuadrotor(kind, num_envs, device=device, seed=seed, env_id_base=env_id_base,
                                     auto_reset=True, track_episodes=True, reading_2d=reading_2d)
@@ -38,9 +38,14 @@ class QuadrotorVecEnv:
         self.observation_space = Box(low=-10.0, high=10.0, shape=(self.env.nS,), dtype=np.float32)
         self._pending = None
         dev = not self.numpy_io
-        self._obs = self.env._new((self.num_envs, self.env.nS), np.float32, dev)
-        self._rew = self.env._new((self.num_envs,), np.float32, dev)
-        self._done = self.env._new((self.num_envs,), np.uint8, dev)
+        # reuse_buffers=True: step_wait() hands out the env's own output buffers (two sets, alternating), valid
+        # until the step after next - no per-step allocation or copy (device tensors only).  The default returns
+        # fresh arrays every step like baselines' DummyVecEnv (whose Runner keeps the returned reward arrays).
+        self.reuse_buffers = bool(reuse_buffers) and dev
+        self._sets = [(self.env._new((self.num_envs, self.env.nS), np.float32, dev),
+                       self.env._new((self.num_envs,), np.float32, dev),
+                       self.env._new((self.num_envs,), np.uint8, dev)) for _ in range(2 if self.reuse_buffers else 1)]
+        self._flip = 0
 
     def reset(self):
         return self.env.reset(layout="aos", device_out=not self.numpy_io)
@@ -49,7 +54,9 @@ class QuadrotorVecEnv:
         if self.numpy_io:
             actions = np.asarray(actions, dtype=np.float32)
         # enqueue on the env's stream; device outputs are filled asynchronously
-        self._pending = self.env.step(actions, layout="aos", out=(self._obs, self._rew, self._done))
+        self._pending = self.env.step(actions, layout="aos", out=self._sets[self._flip])
+        if self.reuse_buffers:
+            self._flip ^= 1
 
     def step_wait(self):
         assert self._pending is not None, "step_async() must precede step_wait()"
@@ -58,8 +65,10 @@ class QuadrotorVecEnv:
         if self.numpy_io:
             done_b = done.astype(bool)
             obs, rew = obs.copy(), rew.copy()
+        elif self.reuse_buffers:
+            done_b = done.view(torch.bool)      # the kernel writes 0 / 1: a bool view, no conversion launch
         else:
-            done_b = done.to(torch.bool)
+            done_b = done.clone().view(torch.bool)
             obs, rew = obs.clone(), rew.clone()
         return obs, rew, done_b, self._infos(done_b)
 

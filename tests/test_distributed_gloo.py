@@ -24,7 +24,7 @@ def _worker(rank, world, port, n_total, out_dir):
     import torch.distributed as dist
 
     import oracle as O
-    from gym_reinmav_amd.distributed import all_gather_episode_stats, all_reduce_totals, shard_range
+    from gym_reinmav_amd.distributed import EpisodeStatsExchange, all_gather_episode_stats, all_reduce_totals, shard_range
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -42,6 +42,13 @@ def _worker(rank, world, port, n_total, out_dir):
         k, rs, nd = O.rollout_random("quad3d", st, sbd[e:e + 1], epi[e:e + 1], 20, 7, int(ids[e]), 0.0, 10.0)
         ret[e], ln[e] = rs, 20
     g_ret, g_len = all_gather_episode_stats(torch.from_numpy(ret), torch.from_numpy(ln), n_total)
+    # the overlapped exchange object bench.py uses (CPU tensors: same code path minus the streams); three posts
+    # cycle both send / receive buffer pairs
+    ex = EpisodeStatsExchange(n_total, "cpu")
+    for k in range(3):
+        ex.post(torch.from_numpy(ret + k), torch.from_numpy(ln + k))
+        r2, l2 = ex.result()
+        assert torch.equal(r2, g_ret + k) and torch.equal(l2, g_len + k)
     tot = all_reduce_totals({"episodes": count, "return_sum": float(ret.sum()), "length_sum": int(ln.sum())})
     np.save(os.path.join(out_dir, f"ret_{rank}.npy"), g_ret.numpy())
     np.save(os.path.join(out_dir, f"len_{rank}.npy"), g_len.numpy())
@@ -50,10 +57,11 @@ def _worker(rank, world, port, n_total, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_all_gather_episode_stats_world2(tmp_path, built):
+@pytest.mark.parametrize("n_total", [37, 36])   # odd: shards of 19 and 18 exercise the padding; even: the no-slicing path
+def test_all_gather_episode_stats_world2(tmp_path, built, n_total):
     import oracle as O
 
-    n_total, world = 37, 2  # odd: shards of 19 and 18 exercise the padding
+    world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
     # single-process result over the whole batch (1 "GPU") must equal the gathered shards
     ids = np.arange(n_total)

@@ -1,0 +1,82 @@
+"""bench.py end to end on the GPU box: the single-process line (roofline fraction is a real HBM fraction, the other
+modes and the CPU baseline are present) and the multi-rank path under torch.distributed.run with two ranks on the
+one GPU (statistics carried by gloo, because RCCL refuses two ranks on one device): n_gpus, the gathered length
+and the shard-invariance of the episode statistics."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(900)
+def test_bench_single_process_line(built):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["steps"] == 300 and j["unit"] == "env-steps/s" and j["scaling"] == "weak"
+    assert "configs[1]" in j["config"]["workload"] and j["config"]["envs_per_gpu"] == 65536
+    assert j["config"]["trajectory_ring"] >= 5
+    rf = j["roofline"]
+    assert 0.0 < rf["frac"] <= 1.0, rf
+    assert rf["bytes_per_launch"] == 65536 * (64 * 61 + 104)
+    assert abs(rf["achieved"] - rf["bytes_per_launch"] / (rf["launch_ms_hip_events"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert j["value"] >= 50e6                                    # BASELINE target: >= 50 M env-steps/s on one GPU
+    om = j["other_modes"]
+    assert "error" not in om, om
+    assert 0.0 < om["step"]["roofline_frac"] <= 1.0 and 0.0 < om["rollout_in_place"]["roofline_frac"] <= 1.0
+    assert om["gym1"]["us_per_iteration_control_plus_step"] > 0 and om["vecenv"]["fresh_tensors_per_step"]["us_per_step"] > 0
+    assert om["policy_rollout"]["fp32"]["env_steps_per_s"] > 0 and om["policy_rollout"]["bf16_mfma"]["env_steps_per_s"] > 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
+
+
+@pytest.mark.timeout(900)
+def test_bench_two_ranks_on_one_gpu(built):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "12", "--warmup", "3", "--cpu-seconds", "0", "--no-secondary", "--chunk", "32"]
+    env = dict(os.environ, RMAV_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                         "--envs-per-gpu", "8192"] + common, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    j2 = _line(r2.stdout)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs-per-gpu", "16384"] + common,
+                        capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    j1 = _line(r1.stdout)
+    assert j2["n_gpus"] == 2 and j1["n_gpus"] == 1
+    assert j2["config"]["envs_total"] == 16384 == j1["config"]["envs_total"]
+    assert "all-gather" in j2["config"]["parallelism"]
+    # keyed by global env id: the sharded run finishes exactly the episodes of the unsharded one
+    assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
+    assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
+    assert 0.0 < j2["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(900)
+def test_bench_under_torchrun_single_rank_rccl(built):
+    """One rank under torch.distributed.run: the real backend (nccl = RCCL), the overlapped per-launch all-gather."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40",
+                        "--warmup", "10", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["config"]["gathered_envs_with_a_finished_episode"] > 0
+    assert 0.0 < j["roofline"]["frac"] <= 1.0

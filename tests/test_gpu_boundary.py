@@ -1,0 +1,171 @@
+"""The boundaries the reference's callers use, through the C ABI: the single-launch control()+step() entry points
+(rmav_control_step / rmav_step_control), the zero-copy pinned path of host-pointer calls, the gym-shaped class's
+cached control(), the VecEnv's buffer reuse, and the RCCL all-gather behind the C ABI (rmav_comm_* /
+rmav_allgather_stats) with one rank."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as O
+from util import CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, random_cases, scaled_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def G(built):
+    import torch
+
+    assert torch.cuda.is_available()
+    import gym_reinmav_amd as g
+
+    return g
+
+
+@pytest.mark.parametrize("n", [1, 77, 5000, 40000])      # 1..5000: pinned zero-copy block; 40000: bulk staging
+@pytest.mark.parametrize("kind", KINDS)
+def test_control_step_equals_control_then_step(G, kind, n):
+    s, _ = random_cases(kind, n, seed=3, wide=False)
+    s *= 0.5
+    a_env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
+    b_env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
+    a_env.set_state(s)
+    b_env.set_state(s)
+    act = a_env.control()
+    obs, rew, done = a_env.step(act)
+    act2, obs2, rew2, done2 = b_env.control_step()
+    assert np.array_equal(act, act2) and np.array_equal(obs, obs2) and np.array_equal(rew, rew2) and np.array_equal(done, done2)
+    # and against the oracle's controller + step
+    ca = O.batch_control(kind, s.astype(np.float64))
+    assert scaled_err(act2, ca).max() <= CTRL_TOL
+    a_env.close()
+    b_env.close()
+
+
+@pytest.mark.parametrize("layout", ["aos", "soa"])
+@pytest.mark.parametrize("n", [1, 300, 70000])
+@pytest.mark.parametrize("kind", KINDS)
+def test_step_control_equals_step_then_control(G, kind, n, layout):
+    import torch
+
+    s, a = random_cases(kind, n, seed=5, wide=False)
+    s *= 0.5
+    envs = [G.BatchedQuadrotor(kind, n, auto_reset=True, track_episodes=True, seed=2) for _ in range(2)]
+    for e in envs:
+        e.set_state(s)
+    to = (lambda x: x) if layout == "aos" else (lambda x: np.ascontiguousarray(x.T))
+    obs, rew, done = envs[0].step(to(a), layout=layout)
+    nxt = envs[0].control(layout=layout)
+    obs2, rew2, done2, nxt2 = envs[1].step_control(to(a), layout=layout)
+    assert np.array_equal(obs, obs2) and np.array_equal(rew, rew2) and np.array_equal(done, done2)
+    assert np.array_equal(nxt, nxt2)
+    # device pointers: same bits
+    envs[0].set_state(s)
+    d_obs, d_rew, d_done, d_nxt = envs[0].step_control(torch.from_numpy(to(a)).cuda(), layout=layout)
+    envs[1].set_state(s)
+    h = envs[1].step_control(to(a), layout=layout)
+    assert np.array_equal(d_nxt.cpu().numpy(), h[3]) and np.array_equal(d_rew.cpu().numpy(), h[1])
+    for e in envs:
+        e.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_gym_env_cached_control_is_the_real_control(G, kind):
+    """The gym-shaped class answers control() from what the last step()'s launch computed; it must equal a fresh
+    evaluation at every point of a closed loop, and be dropped when the state changes behind its back."""
+    env_id = {"quad2d": "quadrotor2d-v0", "quad2d_sl": "quadrotor2d-slungload-v0", "quad3d": "quadrotor3d-v0",
+              "quad3d_sl": "quadrotor3d-slungload-v0"}[kind]
+    env = G.make(env_id, seed=4)
+    env.reset()
+    for i in range(60):
+        a = env.control()
+        fresh = env._batch.control()[0].astype(np.float64)
+        assert np.array_equal(a, fresh), i
+        o, r, d, info = env.step(a)
+        assert o.dtype == np.float64 and isinstance(r, float) and isinstance(d, bool) and info == {}
+        assert np.array_equal(o, env.state)
+        if d:
+            env.reset()
+            assert not env._ctrl_valid
+    st = env.state * 0.5
+    env.state = st
+    assert not env._ctrl_valid
+    assert scaled_err(env.control(), O.batch_control(kind, st[None].astype(np.float32).astype(np.float64))[0]).max() <= CTRL_TOL
+    with pytest.raises(ValueError):
+        env.step(np.zeros(NA[kind] + 1))
+    env.close()
+
+
+def test_vec_env_reuse_buffers(G):
+    import torch
+
+    n = 4096
+    a = G.QuadrotorVecEnv("quadrotor3d-v0", n, seed=6)
+    b = G.QuadrotorVecEnv("quadrotor3d-v0", n, seed=6, reuse_buffers=True)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    act = torch.empty((n, 4), device="cuda").uniform_(0, 10)
+    prev = None
+    for t in range(40):
+        ra, rb = a.step(act), b.step(act)
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[1], rb[1]) and torch.equal(ra[2], rb[2])
+        assert rb[2].dtype == torch.bool and ra[2].dtype == torch.bool
+        if prev is not None:   # the previous step's tensors are still intact (two buffer sets alternate)
+            assert torch.equal(prev[0], prev_copy[0]) and torch.equal(prev[1], prev_copy[1])
+        prev, prev_copy = rb, (rb[0].clone(), rb[1].clone())
+    a.close()
+    b.close()
+
+
+def test_rccl_allgather_behind_the_c_abi_single_rank(G):
+    """rmav_comm_* + rmav_allgather_stats with one rank (RCCL refuses two ranks on one device): the gathered arrays
+    equal the handle's own per-env statistics; shard mismatches and missing tracking are rejected."""
+    code = f"""
+import ctypes as C, sys
+sys.path.insert(0, {os.path.join(ROOT, 'reinmav-gym_amd')!r})
+import numpy as np, torch
+import gym_reinmav_amd as g
+A = g._abi
+L = A.lib()
+n = 4099
+env = g.BatchedQuadrotor('quad3d', n, seed=1)
+env.rollout(96, mode='random', want=())
+uid = (C.c_char * A.COMM_ID_BYTES)()
+A.check(L.rmav_comm_unique_id(uid))
+comm = C.c_void_p()
+A.check(L.rmav_comm_create(C.byref(comm), uid, 0, 1, 0))
+ret = torch.empty(n, dtype=torch.float32, device='cuda'); ln = torch.empty(n, dtype=torch.int32, device='cuda')
+for _ in range(3):
+    A.check(L.rmav_allgather_stats(env._h, comm, n, C.c_void_p(ret.data_ptr()), C.c_void_p(ln.data_ptr())))
+env.sync()
+eb = env.episode_buffers()
+assert np.array_equal(ret.cpu().numpy(), eb['last_return']) and np.array_equal(ln.cpu().numpy(), eb['last_length'])
+assert (eb['last_length'] > 0).any()
+assert L.rmav_allgather_stats(env._h, comm, n + 1, C.c_void_p(ret.data_ptr()), C.c_void_p(ln.data_ptr())) == A.ERR_INVALID
+e2 = g.BatchedQuadrotor('quad3d', n, track_episodes=False)
+assert L.rmav_allgather_stats(e2._h, comm, n, C.c_void_p(ret.data_ptr()), C.c_void_p(ln.data_ptr())) == A.ERR_INVALID
+assert L.rmav_comm_destroy(comm) == 0 and L.rmav_comm_destroy(None) == A.ERR_INVALID
+print('rccl abi ok')
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl abi ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_pack_stats_is_the_allgather_payload(G):
+    import torch
+
+    n, cmax = 1000, 1024
+    env = G.BatchedQuadrotor("quad3d", n, seed=3)
+    env.rollout(80, mode="random", want=())
+    send = torch.full((2 * cmax,), -7, dtype=torch.int32, device="cuda")
+    env.pack_stats(send)
+    eb = env.episode_buffers()
+    s = send.cpu().numpy()
+    assert np.array_equal(s[:n].view(np.float32), eb["last_return"]) and np.array_equal(s[cmax:cmax + n], eb["last_length"])
+    assert (s[n:cmax] == 0).all() and (s[cmax + n:] == 0).all()
+    env.close()

@@ -336,6 +336,39 @@ def test_batch_major_trajectory_of_a_big_launch(G, kind, n, T):
     assert torch.equal(aos["state"], soa["state"])
 
 
+@pytest.mark.parametrize("mode", ["random", "controller"])
+@pytest.mark.parametrize("n,T", [(63, 9), (64 + 29, 16), (20037, 24)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_ragged_last_wavefront_writes_nothing_out_of_bounds(G, kind, n, T, mode):
+    """Every trajectory buffer of a fused launch sits in front of a guard region of sentinels; with n % 64 != 0 the
+    clone lanes of the last wavefront (two-wavefront kernel: batch-major obs drained through a range-checked buffer
+    descriptor) must leave the guards untouched, and interior rows must equal the SoA launch's (a stray clone row of
+    step k would land in rows 0.. of step k+1)."""
+    import torch
+
+    guard = 4096
+    sentinel = -12345.0
+    res = {}
+    for layout in ("soa", "aos"):
+        env = G.BatchedQuadrotor(kind, n, seed=11, auto_reset=True, track_episodes=True)
+        sizes = {"actions": T * n * NA[kind], "obs": T * n * NS[kind], "rew": T * n}
+        raw = {k: torch.full((v + guard,), sentinel, dtype=torch.float32, device="cuda") for k, v in sizes.items()}
+        raw["done"] = torch.full((T * n + guard,), 77, dtype=torch.uint8, device="cuda")
+        shp = (lambda d: (T, d, n)) if layout == "soa" else (lambda d: (T, n, d))
+        out = {"actions": raw["actions"][:sizes["actions"]].view(shp(NA[kind])), "obs": raw["obs"][:sizes["obs"]].view(shp(NS[kind])),
+               "rew": raw["rew"][:T * n].view(T, n), "done": raw["done"][:T * n].view(T, n)}
+        env.rollout(T, mode=mode, layout=layout, want=("actions", "obs", "rew", "done"), device_out=True, out=out)
+        torch.cuda.synchronize()
+        for k, v in sizes.items():
+            assert bool((raw[k][v:] == sentinel).all()), (layout, k)
+        assert bool((raw["done"][T * n:] == 77).all()), layout
+        res[layout] = out
+        env.close()
+    assert torch.equal(res["aos"]["obs"], res["soa"]["obs"].transpose(1, 2))
+    assert torch.equal(res["aos"]["actions"], res["soa"]["actions"].transpose(1, 2))
+    assert torch.equal(res["aos"]["rew"], res["soa"]["rew"]) and torch.equal(res["aos"]["done"], res["soa"]["done"])
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_non_finite_inputs_follow_the_reference(G, kind):
     """The reference has no NaN / inf guard: NaN propagates, `NaN > limit` is False so the env is

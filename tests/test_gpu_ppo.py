@@ -211,6 +211,66 @@ def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n):
     env.close()
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_c5_size_policy_rollout(G, bf16):
+    """BASELINE configs[4] (C5)'s per-GPU shard at full size: quadrotor3d-v0, 65 536 envs x 32-step rollouts with the
+    policy inside the kernel (fp32 and bf16-MFMA actors).  Every env step of a 4 096-env sample is checked against
+    the oracle from the recorded (obs, action) - including the auto-reset states - and the values / log-probs of the
+    whole batch against the torch policy; the GAE pass over the [32][65 536] result is checked against the torch loop."""
+    import torch
+    from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy, gae
+
+    torch.manual_seed(4)
+    kind, N, T, seed = "quad3d", 65536, 32, 17
+    env = G.BatchedQuadrotor(kind, N, seed=seed)
+    pol = MlpPolicy(env.nS, env.nA, init_logstd=0.5).cuda()
+    with torch.no_grad():
+        pol.pi[2].weight.mul_(30.0)
+        pol.pi[2].bias.uniform_(0.5, 4.0)          # thrust around hover, so episodes last a while and still end
+        pol.vf[2].bias.uniform_(-0.5, 0.5)
+    ro = FusedPolicyCollector(env, pol, T, bf16_mfma=bf16)
+    sample = np.arange(0, N, 16)                    # 4 096 envs, every wavefront represented
+    rc = env.get_reset_counts()
+    for it in range(2):
+        ro.collect()
+        torch.cuda.synchronize()
+        obs, act = ro.obs[:, :, sample].cpu().numpy(), ro.act[:, :, sample].cpu().numpy()
+        rew, done = ro.rew[:, sample].cpu().numpy(), ro.done[:, sample].cpu().numpy().astype(bool)
+        rcs = rc[sample].copy()
+        for t in range(T):
+            o2, r, d, _ = O.batch_step(kind, obs[t].T.astype(np.float64), act[t].T.astype(np.float64))
+            ok = near_threshold(kind, o2)
+            assert np.array_equal(done[t] | ok, d | ok)
+            alive = ~done[t] & ~d
+            assert scaled_err(obs[t + 1].T[alive], o2[alive]).max() <= TOL
+            assert scaled_err(rew[t][alive], r[alive]).max() <= TOL
+            if done[t].any():
+                assert np.array_equal(obs[t + 1].T[done[t]], O.reset_states(kind, seed, sample[done[t]], rcs[done[t]]))
+            rcs += done[t].astype(np.uint32)
+        rc = rc + ro.done.sum(0).cpu().numpy().astype(np.uint32)
+        assert np.array_equal(env.get_reset_counts(), rc)
+        with torch.no_grad():
+            mean, val = pol(ro.obs[:T].permute(1, 0, 2).reshape(env.nS, -1))
+            mean, val = mean.reshape(env.nA, T, N), val.reshape(T, N)
+            v_last = pol(ro.obs[T])[1]
+            std = torch.exp(pol.logstd)[:, None, None]
+            tol = (3e-2 if bf16 else 2e-5) * max(1.0, float(val.abs().max()))
+            assert (ro.val[:T] - val).abs().max() < tol and (ro.val[T] - v_last).abs().max() < tol
+            if not bf16:
+                z = (ro.act.permute(1, 0, 2) - mean) / std
+                logp_ref = -0.5 * (z * z).sum(0) - pol.logstd.sum() - 0.5 * env.nA * np.log(2 * np.pi)
+                assert (ro.logp - logp_ref).abs().max() < 2e-3
+            assert bool(torch.isfinite(ro.logp).all())
+            # GAE kernel over the full-size trajectory vs the torch fp32 loop
+            adv, ret = env.gae(ro.rew, ro.done, ro.val, 0.99, 0.95)
+            adv_t, ret_t = gae(ro.rew, ro.val, ro.done, 0.99, 0.95)
+            scale = max(1.0, float(adv_t.abs().max()))
+            assert (adv - adv_t).abs().max() < 1e-5 * scale and (ret - ret_t).abs().max() < 1e-5 * scale
+        ro.roll_over()
+    assert int(ro.done.sum()) > 0
+    env.close()
+
+
 def test_run_cli_trains_saves_and_plays(G, tmp_path):
     """python -m gym_reinmav_amd.run ... (the reference's `python -m gym_reinmav.run --alg=ppo2 --env=... --play`)."""
     import json

@@ -70,3 +70,19 @@ def test_run_cli_argument_parsing():
     kw = parse_unknown(unknown)
     assert kw == {"nsteps": 16, "lr": 1e-3, "cliprange": 0.1, "load_path": "/tmp/x.pt"}
     assert parse_unknown(["--x=__import__('os').system('true')"]) == {"x": "__import__('os').system('true')"}   # not evaluated
+
+
+def test_bench_byte_accounting():
+    """bench.py's roofline bytes for the fused rollout: trajectory out per env-step + state / bookkeeping per launch."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    # quadrotor3d: 16 B actions + 40 B obs + 4 B reward + 1 B done = 61 B per env-step; 80 B state in/out + 16 B episode
+    # accumulators in/out + 8 B steps_beyond_done / reset counter in = 104 B per launch
+    assert b.fused_bytes_per_launch(65536, 64, 10, 4) == 65536 * (64 * 61 + 104)
+    assert b.fused_bytes_per_launch(1, 1, 16, 4) == 4 * 21 + 1 + 8 * 16 + 24
+    assert b.HBM_PEAK_GBS == 8000.0
