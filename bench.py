@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
     ap.add_argument("--in-place", action="store_true", help="rollout mode: rewrite ONE trajectory buffer set (cache-assisted)")
     ap.add_argument("--ring", type=int, default=0, help="rollout mode: number of trajectory buffer sets (0 = >= 5 and > 1.5 GB)")
+    ap.add_argument("--action-ring", type=int, default=64, help="step mode: number of pre-generated action buffers")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
     ap.add_argument("--secondary", default="in_place,step,gym1,vecenv,policy",
@@ -171,7 +172,10 @@ def main():
         gloo = use_dist and dist.get_backend() == "gloo"
         exchange = EpisodeStatsExchange(n_total, "cpu" if gloo else dev) if use_dist else None
 
-        RING = 512  # step mode: ring of pre-generated action buffers (fresh random actions every launch)
+        # step mode: ring of pre-generated action buffers (fresh random actions every launch).  64 buffers = 67 MB at
+        # 65 536 envs: like the actions a policy kernel has just written, they are still on chip (L2 / Infinity Cache)
+        # when the step launch reads them.  (512 buffers - every action read a cold HBM miss - cost +0.45 us per launch.)
+        RING = args.action_ring
 
         def traj_bytes(chunk):
             return n * chunk * (4 * (nS + nA + 1) + 1)
@@ -340,6 +344,8 @@ def main():
                                 if args.mode == "rollout"
                                 else "one step = one launch = 1 env-step per env, actions read from a device buffer, "
                                      "obs/reward/done written")),
+                "kind": kind,
+                "actions": args.actions,
                 "envs_per_gpu": n,
                 "envs_total": n_total,
                 "env_steps_per_launch_per_env": per_launch,

@@ -68,6 +68,7 @@ struct rmav_env_s {
     int32_t *ep_len, *last_len;
     Totals *totals;
     double *env_time;  // RMAV_REINMAV only
+    void *arena;       // ONE allocation behind all of the arrays above (see rmav_create)
     float *pe[3];      // per-env constants (rmav_set_env_param), nullptr = shared
     // scratch for host-pointer calls and layout conversion (grown on demand)
     void *scratch;
@@ -119,7 +120,6 @@ int check_params(const rmav_params &q) {
 inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
 
 // Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
-constexpr int64_t kSplitMaxEnvs = 65536;   // measured: see DESIGN.md section 4
 
 int block_size() {
     static int b = [] {
@@ -176,9 +176,14 @@ int ensure_pinned(rmav_handle h, size_t bytes) {
     return RMAV_OK;
 }
 
-// Cache policy of the trajectory stores for one launch (thresholds measured, see rmav_kernels.hpp): bytes a launch
-// writes = n_steps * N * (4 nA [actions] + 4 nS [obs] + 4 [reward] + 1 [done]).  RMAV_STORE_POLICY=0|1|2 overrides.
-int pick_store_policy(rmav_handle h, const RolloutArgs &a) {
+// Cache policy of the trajectory stores for one launch.  Measured with COLD trajectory buffers (bench.py's ring of
+// buffer sets; profiles/r02/policy_split_sweep.md), 64-step launches, every kind, 65 536 .. 1 048 576 envs:
+//   two-wavefront kernel : write-through (sc0 sc1) is best or within 1 % of best everywhere
+//   one-wavefront kernel : non-temporal (nt) is best from 131 072 envs up (+3..7 % over the default policy, which is
+//                          never the best choice for a fused launch); small trajectories that stay in the Infinity
+//                          Cache for their consumer keep write-through
+// Single-step and very short launches use the default policy.  RMAV_STORE_POLICY=0|1|2 overrides.
+int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
     static const int forced = [] {
         const char *e = getenv("RMAV_STORE_POLICY");
         return e ? atoi(e) : -1;
@@ -193,14 +198,22 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a) {
     const double bytes = per_step * (double)h->n * (double)a.n_steps;
     if (a.flags & F_AOS) {   // batch-major trajectories: LDS-transposed obs stores once the launch is big (RMAV_STORE_POLICY=3: always, 0: never)
         if (forced == 0) return ST_DEFAULT;
+        if (split) return ST_WRITE_THROUGH;   // the memory wavefront drains batch-major tiles itself
         // measured (profiles/r01/layout_sweep.md): pays from 131 072 envs x 64 steps (512 MB), costs 10-15 % at 65 536 (256 MB)
-        return (a.obs_out && (bytes >= 448.0e6 || forced == ST_AOS_LDS)) ? ST_AOS_LDS : ST_DEFAULT;
+        return (a.obs_out && (bytes >= 448.0e6 || forced == ST_AOS_LDS)) ? ST_AOS_LDS : ST_WRITE_THROUGH;
     }
-    if (bytes >= 768.0e6) return ST_STREAM;
-    if (bytes <= 320.0e6) return ST_WRITE_THROUGH;
-    return ST_DEFAULT;
+    if (split) return ST_WRITE_THROUGH;
+    return bytes <= 192.0e6 ? ST_WRITE_THROUGH : ST_STREAM;
 }
 
+// Two-wavefront (integrator + memory wavefront) kernel or one wavefront per 64 envs?  The second wavefront pays while
+// the batch leaves the SIMDs under-occupied (one wavefront per SIMD = 65 536 envs) and costs occupancy and LDS beyond
+// that.  Crossover batch sizes per kind and action source, measured on cold trajectory buffers in steps of 16 384 envs
+// with four pairs per workgroup (profiles/r02/split_crossover.md; the two-wavefront kernel is used BELOW the entry,
+// which sits halfway between its last win and its first loss):
+//                                            quad2d   quad2d_sl  quad3d  quad3d_sl
+constexpr int64_t kSplitBelowRandom[4]     = {139264,  122880,    122880, 73728};   // helper draws the actions and drains
+constexpr int64_t kSplitBelowController[4] = {106496,  73728,     106496, 73728};   // helper only drains
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     const typename Env<K>::P p = derive_env<K>(h->params);
@@ -209,10 +222,11 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
-    if constexpr (is_split(MODE)) {   // two wavefronts (integrator + memory wavefront) per 64 envs
+    if constexpr (is_split(MODE)) {   // (integrator, memory wavefront) pairs, kSplitGroup of them per workgroup
         using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, MODE == ACT_RANDOM_SPLIT>;
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + 63) / 64)), dim3(128),
-                           sizeof(float) * Tile::WORDS, h->stream, a, p, pc);
+        constexpr int64_t per_wg = 64 * kSplitGroup;
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * kSplitGroup),
+                           sizeof(float) * Tile::WORDS * kSplitGroup, h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     }
@@ -220,20 +234,15 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     return RMAV_OK;
 }
 
-// Random-action rollouts of small batches run with the action draws on a second wavefront (ACT_RANDOM_SPLIT in
-// rmav_kernels.hpp): it pays while the batch leaves SIMDs under-occupied.  RMAV_SPLIT=0|1 overrides.
-bool use_split(rmav_handle h, const RolloutArgs &a, int st, bool draws = true) {
+// RMAV_SPLIT=0|1 overrides the table.
+bool use_split(rmav_handle h, const RolloutArgs &a, bool draws = true) {
     static const int forced = [] {
         const char *e = getenv("RMAV_SPLIT");
         return e ? atoi(e) : -1;
     }();
-    if (a.n_steps < 8 || st == ST_AOS_LDS) return false;
+    if (a.n_steps < 8 || h->kind > RMAV_QUAD3D_SL) return false;
     if (forced == 0 || forced == 1) return forced == 1;
-    // measured in steady state (profiles/r01/split_ab.md): +10..21 % at 65 536 envs for every kind; at 131 072 only the
-    // 2-D kinds still gain (+3..9 %), the 3-D ones lose 5..22 %
-    // controller-driven rollouts (the helper only drains): +14..28 % at 65 536 envs, a loss at 131 072 for every kind
-    const bool two_d = h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL;
-    return h->n <= ((two_d && draws) ? 2 * kSplitMaxEnvs : kSplitMaxEnvs);
+    return h->n < (draws ? kSplitBelowRandom : kSplitBelowController)[h->kind];
 }
 
 template <int K, int MODE>
@@ -242,26 +251,17 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
         return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
     } else {
-        const int st = pick_store_policy(h, a);
-        if constexpr (MODE == ACT_RANDOM && K != REINMAV) {
-            if (use_split(h, a, st)) {
-                switch (st) {
-                case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_WRITE_THROUGH>(h, a);
-                case ST_STREAM: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_STREAM>(h, a);
-                default: return launch_rollout_kms<K, ACT_RANDOM_SPLIT, ST_DEFAULT>(h, a);
+        if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER) && K != REINMAV) {
+            constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : ACT_CONTROLLER_SPLIT;
+            if (use_split(h, a, MODE == ACT_RANDOM)) {
+                switch (pick_store_policy(h, a, true)) {
+                case ST_STREAM: return launch_rollout_kms<K, SMODE, ST_STREAM>(h, a);
+                case ST_DEFAULT: return launch_rollout_kms<K, SMODE, ST_DEFAULT>(h, a);
+                default: return launch_rollout_kms<K, SMODE, ST_WRITE_THROUGH>(h, a);
                 }
             }
         }
-        if constexpr (MODE == ACT_CONTROLLER && K != REINMAV) {
-            if (use_split(h, a, st, false)) {
-                switch (st) {
-                case ST_WRITE_THROUGH: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_WRITE_THROUGH>(h, a);
-                case ST_STREAM: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_STREAM>(h, a);
-                default: return launch_rollout_kms<K, ACT_CONTROLLER_SPLIT, ST_DEFAULT>(h, a);
-                }
-            }
-        }
-        switch (st) {
+        switch (pick_store_policy(h, a, false)) {
         case ST_WRITE_THROUGH: return launch_rollout_kms<K, MODE, ST_WRITE_THROUGH>(h, a);
         case ST_STREAM: return launch_rollout_kms<K, MODE, ST_STREAM>(h, a);
         case ST_AOS_LDS: return launch_rollout_kms<K, MODE, ST_AOS_LDS>(h, a);
@@ -412,8 +412,7 @@ template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t cou
 }
 
 void free_all(rmav_handle h) {
-    void *ptrs[] = {h->state, h->sbd, h->reset_cnt, h->ep_ret, h->last_ret, h->ep_len, h->last_len,
-                    h->totals, h->env_time, h->pe[0], h->pe[1], h->pe[2], h->scratch};
+    void *ptrs[] = {h->arena, h->pe[0], h->pe[1], h->pe[2], h->scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -549,21 +548,41 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     }
     const size_t n = (size_t)n_envs;
     const int nS = kStateDim[kind];
-    bool ok = hipMalloc((void **)&h->state, n * nS * sizeof(float)) == hipSuccess &&
-              hipMalloc((void **)&h->sbd, n * sizeof(int32_t)) == hipSuccess &&
-              hipMalloc((void **)&h->reset_cnt, n * sizeof(uint32_t)) == hipSuccess &&
-              hipMalloc((void **)&h->totals, n_waves(n_envs) * sizeof(Totals)) == hipSuccess;
-    if (ok && kind == RMAV_REINMAV) ok = hipMalloc((void **)&h->env_time, n * sizeof(double)) == hipSuccess;
-    if (ok && (flags & RMAV_F_TRACK_EPISODES)) {
-        ok = hipMalloc((void **)&h->ep_ret, n * sizeof(float)) == hipSuccess &&
-             hipMalloc((void **)&h->last_ret, n * sizeof(float)) == hipSuccess &&
-             hipMalloc((void **)&h->ep_len, n * sizeof(int32_t)) == hipSuccess &&
-             hipMalloc((void **)&h->last_len, n * sizeof(int32_t)) == hipSuccess;
-    }
-    if (!ok) {
-        (void)hipGetLastError();
-        free_all(h);
-        return fail(RMAV_ERR_ALLOC, "device allocation failed for %lld envs", (long long)n_envs);
+    // One arena for every per-env array.  A single-step launch at 65 536 envs is latency-bound and touches ten
+    // small arrays (256 KB each); as separate hipMalloc blocks each of them sits in its own small-page mapping and
+    // every launch pays their address translations, while one 2 MiB-aligned block is covered by a few large
+    // fragments.  Sub-arrays start on 4 KiB boundaries.
+    {
+        auto up = [](size_t b) { return (b + 4095) & ~(size_t)4095; };
+        const bool tr = (flags & RMAV_F_TRACK_EPISODES) != 0;
+        size_t off = 0;
+        const size_t o_state = off; off += up(n * nS * sizeof(float));
+        const size_t o_sbd = off; off += up(n * sizeof(int32_t));
+        const size_t o_rc = off; off += up(n * sizeof(uint32_t));
+        const size_t o_tot = off; off += up(n_waves(n_envs) * sizeof(Totals));
+        const size_t o_time = off; off += (kind == RMAV_REINMAV) ? up(n * sizeof(double)) : 0;
+        const size_t o_er = off; off += tr ? up(n * sizeof(float)) : 0;
+        const size_t o_lr = off; off += tr ? up(n * sizeof(float)) : 0;
+        const size_t o_el = off; off += tr ? up(n * sizeof(int32_t)) : 0;
+        const size_t o_ll = off; off += tr ? up(n * sizeof(int32_t)) : 0;
+        if (hipMalloc(&h->arena, off) != hipSuccess) {
+            (void)hipGetLastError();
+            h->arena = nullptr;
+            free_all(h);
+            return fail(RMAV_ERR_ALLOC, "device allocation of %zu bytes failed for %lld envs", off, (long long)n_envs);
+        }
+        char *b = (char *)h->arena;
+        h->state = (float *)(b + o_state);
+        h->sbd = (int32_t *)(b + o_sbd);
+        h->reset_cnt = (uint32_t *)(b + o_rc);
+        h->totals = (Totals *)(b + o_tot);
+        if (kind == RMAV_REINMAV) h->env_time = (double *)(b + o_time);
+        if (tr) {
+            h->ep_ret = (float *)(b + o_er);
+            h->last_ret = (float *)(b + o_lr);
+            h->ep_len = (int32_t *)(b + o_el);
+            h->last_len = (int32_t *)(b + o_ll);
+        }
     }
     hipError_t e = hipMemsetAsync(h->sbd, 0xFF, n * sizeof(int32_t), h->stream);  // -1 = None
     if (e == hipSuccess) e = hipMemsetAsync(h->reset_cnt, 0, n * sizeof(uint32_t), h->stream);

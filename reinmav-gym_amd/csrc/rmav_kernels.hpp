@@ -44,6 +44,17 @@ constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BU
 #define RMAV_SPLIT_CHUNK 2
 #endif
 constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
+// Split modes: (integrator, memory wavefront) pairs per workgroup.  The pairs of one workgroup own ADJACENT 64-env
+// groups and run on one CU, so its memory wavefronts store adjacent 256-byte segments of every trajectory column
+// (the store-only microbenchmark tools/micro/store_patterns.hip absorbs 1 KiB-per-CU segments 6 % faster than
+// 256-byte ones at 65 536 envs on cold buffers).  Measured on cold trajectory buffers, 64-step launches, 1 -> 4 pairs
+// (profiles/r02/split_group_ab.md): quadrotor3d 46.2 -> 45.5 us at 65 536 envs, slung load 74.3 -> 73.4, 2-D 45.5 ->
+// 43.6, 2-D slung load 67.8 -> 65.1; at 131 072 envs 3-D slung load 180 -> 148 us.  2 pairs are slower than either
+// (both integrators land on one pair of SIMDs).
+#ifndef RMAV_SPLIT_GROUP
+#define RMAV_SPLIT_GROUP 4
+#endif
+constexpr int kSplitGroup = RMAV_SPLIT_GROUP;
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int A_HALF = DRAWS ? kSplitChunk * NA * 64 : 0, A_WORDS = 2 * A_HALF;
     // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
@@ -155,14 +166,18 @@ __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t sof
 }
 
 template <int K, int MODE, int ST = ST_DEFAULT>
-__global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
+__global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroup : kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;
     // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
     constexpr bool SPLIT = is_split(MODE), DRAWS = (MODE == ACT_RANDOM_SPLIT);
-    const uint32_t gi = SPLIT ? blockIdx.x * 64u + (threadIdx.x & 63u)
-                                                   : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gi = SPLIT ? blockIdx.x * (64u * kSplitGroup) + (threadIdx.x & (64u * kSplitGroup - 1u))
+                              : blockIdx.x * blockDim.x + threadIdx.x;
+    // SPLIT: this pair's hand-over tiles
+    [[maybe_unused]] float *lds_p = lds_w;
+    if constexpr (SPLIT && kSplitGroup > 1)
+        lds_p = lds_w + __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) % kSplitGroup) * SplitTile<NS, NA, DRAWS>::WORDS;
     const int64_t n = a.n;
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
@@ -201,14 +216,15 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     // hands the action over with its other outputs; the helper only drains.
     if constexpr (SPLIT) {
         using ST_ = SplitTile<NS, NA, DRAWS>;
-        if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 1u) {
+        if ((uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= (uint32_t)kSplitGroup) {
             const uint64_t env_id = a.env_base + (uint64_t)li;
             const uint32_t lane = threadIdx.x & 63u;
             const int32_t T = a.n_steps;
             const int32_t nc = (T + kSplitChunk - 1) / kSplitChunk;
             // batch-major obs: output dword 64 q + lane of this wavefront is component e % NS of its env e / NS
             const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
-            const uint32_t n_here = (uint64_t)wave_first + 64u <= (uint64_t)n ? 64u : (uint32_t)(n - wave_first);
+            const uint32_t n_here = (uint64_t)wave_first + 64u <= (uint64_t)n ? 64u
+                                    : ((uint64_t)wave_first < (uint64_t)n ? (uint32_t)(n - wave_first) : 0u);
             const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
             uint32_t aos_rd[NS];
 #pragma unroll
@@ -217,7 +233,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 aos_rd[q] = (e / NS) * ST_::OBS_STRIDE + (e % NS);
             }
             auto fill = [&](int32_t c) {   // actions of chunk c: draw, hand over, write the action trajectory
-                float *buf = lds_w + (c & 1) * ST_::A_HALF + lane;
+                float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
 #pragma unroll
                 for (int j = 0; j < kSplitChunk; ++j) {
                     const int32_t k = c * kSplitChunk + j;
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 }
             };
             auto drain = [&](int32_t c) {  // obs / reward / done of chunk c: LDS -> trajectory
-                const float *buf = lds_w + ST_::A_WORDS + (c & 1) * ST_::O_HALF + lane;
+                const float *buf = lds_p + ST_::A_WORDS + (c & 1) * ST_::O_HALF + lane;
 #pragma unroll
                 for (int j = 0; j < kSplitChunk; ++j) {
                     const int32_t k = c * kSplitChunk + j;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
                 if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
-                const float *buf = lds_w + ((k / kSplitChunk) & 1) * SplitTile<NS, NA, true>::A_HALF +
+                const float *buf = lds_p + ((k / kSplitChunk) & 1) * SplitTile<NS, NA, true>::A_HALF +
                                    (k % kSplitChunk) * (NA * 64) + (threadIdx.x & 63u);
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
@@ -564,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
                 // hand obs / reward / done (and the controller's action) to the memory wavefront; it drains this
                 // half two barriers later
                 using ST_ = SplitTile<NS, NA, DRAWS>;
-                float *row = lds_w + ST_::A_WORDS + ((k / kSplitChunk) & 1) * ST_::O_HALF + (k % kSplitChunk) * ST_::O_ROW +
+                float *row = lds_p + ST_::A_WORDS + ((k / kSplitChunk) & 1) * ST_::O_HALF + (k % kSplitChunk) * ST_::O_ROW +
                              (threadIdx.x & 63u);
                 if (obs_out) {
                     if (aos) {   // env-major for the batch-major drain
@@ -690,6 +706,46 @@ __global__ __launch_bounds__(kBlock) void k_rollout(const RolloutArgs a, const t
     }
 }
 
+// reset_state<K> for the lanes of a wavefront that need it, computed cooperatively (all 64 lanes must be active).
+// Philox4x32-10 is ~20 quarter-rate 32x32->64 multiplies per call and reset_state needs ceil(nS / 4) calls (the counter
+// word c3 selects the block of four components); executed by a whole wavefront for the one or two lanes whose env has
+// just terminated, that is ~1 us of a ~4.5 us single-step launch at one wavefront per SIMD.  Here every group of four
+// lanes serves ONE terminating lane instead: lane 4g + b draws block b for the g-th terminating lane (env id and reset
+// counter of that lane, so the same counters and the same bits), and the terminating lane picks its components up
+// with ds_bpermute.  One Philox call per wavefront covers up to 16 terminations (more: the loop goes round again).
+template <int K>
+__device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_lane0, uint32_t rc, bool need,
+                                                 float (&s)[Dims<K>::NS]) {
+    constexpr int NS = Dims<K>::NS;
+    static_assert(NS <= 16, "four lanes x four components per terminating lane");
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t m = __ballot(need);                      // wave-uniform
+    while (m) {
+        // source lane of this lane's group: the (lane >> 2)-th set bit of m, if there is one
+        uint64_t t = m;
+        for (uint32_t q = lane >> 2; q != 0 && t != 0; --q) t &= t - 1;
+        const uint32_t src = t ? (uint32_t)__builtin_ctzll(t) : 0u;
+        const uint32_t rc_src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)rc);
+        const uint64_t env = env_id_lane0 + src;
+        uint32_t r[4];
+        philox4x32_10((uint32_t)env, (uint32_t)(env >> 32), rc_src, (1u << 24) | (lane & 3u), (uint32_t)seed,
+                      (uint32_t)(seed >> 32), r);
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = rfma(2.0f, u01(r[i]), -1.0f);
+        // a needing lane with k set bits of m below it (k < 16) takes component c from lane 4k + c / 4, register c % 4
+        const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const bool mine = need && ((m >> lane) & 1ull) && k < 16u;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) {
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)((4u * (k & 15u) + (uint32_t)(c >> 2)) << 2),
+                                                                                  __builtin_bit_cast(int, u[c & 3])));
+            if (mine) s[c] = v;
+        }
+        for (int q = 0; q < 16 && m; ++q) m &= m - 1;   // the 16 lowest set bits are served
+    }
+}
+
 // One env-step per launch (rmav_step, rmav_step_control, the fused = 0 loop of rmav_rollout with caller actions).
 // At BASELINE's 65 536 envs such a launch is latency-bound (a few us against 0.8 us of HBM time), so this is
 // k_rollout<K, ACT_BUFFER> at n_steps = 1 re-cut for latency, same arithmetic and same bits:
@@ -710,7 +766,9 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     const bool valid = gi < (uint64_t)n;
-    const uint32_t li = gi;
+    // lanes past the end of the batch are clones of env N-1 that store nothing: all 64 lanes of every wavefront
+    // stay active, which the cooperative reset needs
+    const uint32_t li = valid ? gi : (uint32_t)n - 1u;
     const uint32_t col = (uint32_t)n * 4u, off = li * 4u;
     const bool aos = (a.flags & F_AOS) != 0;
     const bool track = (a.flags & F_TRACK) != 0;
@@ -721,52 +779,51 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     Totals tot = {0ull, 0.0, 0ull};
     if (track) tot = a.totals[wave];
 
+    const rsrc_t r_state = make_rsrc(a.state);
+    float s[NS], act[NA];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
+    if (aos) {
+        const float *src = a.act_in + (int64_t)li * NA;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) act[c] = src[c];
+    } else {
+        const rsrc_t r = make_rsrc(a.act_in);
+#pragma unroll
+        for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * col);
+    }
+    float er = 0.0f;
+    int32_t el = 0;
+    if (track) {
+        er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+        el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+    }
+    int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+    const uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+    typename Env<K>::P pl = p_shared;
+    ParamsT<double> pcl = pc_shared;
+    if (a.pe[0] || a.pe[1] || a.pe[2]) {
+        const double m = a.pe[0] ? (double)a.pe[0][li] : (double)pc_shared.mass;
+        const double ml = a.pe[1] ? (double)a.pe[1][li] : (double)pc_shared.load_mass;
+        const double L = a.pe[2] ? (double)a.pe[2][li] : (double)pc_shared.L;
+        override_params(pl, m, ml, L);
+        override_params(pcl, m, ml, L);
+    }
+
+    float dist = 0.0f;
+    bool done;
+    Env<K>::step(s, act, pl, dist, done);
+    // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
+    float r = -dist;
+    if (done) {
+        r = (sb < 0) ? 1.0f : 0.0f;
+        sb = (sb < 0) ? 0 : sb + 1;
+    }
     bool fin = false;
     float fin_ret = 0.0f;
     int32_t fin_len = 0;
+    // everything that does not need the reset state goes out first
     if (valid) {
-        const rsrc_t r_state = make_rsrc(a.state);
-        float s[NS], act[NA];
-#pragma unroll
-        for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
-        if (aos) {
-            const float *src = a.act_in + (int64_t)li * NA;
-#pragma unroll
-            for (int c = 0; c < NA; ++c) act[c] = src[c];
-        } else {
-            const rsrc_t r = make_rsrc(a.act_in);
-#pragma unroll
-            for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * col);
-        }
-        float er = 0.0f;
-        int32_t el = 0;
-        if (track) {
-            er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-            el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
-        }
-        int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-        uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
-        const uint64_t env_id = a.env_base + (uint64_t)li;
-        typename Env<K>::P pl = p_shared;
-        ParamsT<double> pcl = pc_shared;
-        if (a.pe[0] || a.pe[1] || a.pe[2]) {
-            const double m = a.pe[0] ? (double)a.pe[0][li] : (double)pc_shared.mass;
-            const double ml = a.pe[1] ? (double)a.pe[1][li] : (double)pc_shared.load_mass;
-            const double L = a.pe[2] ? (double)a.pe[2][li] : (double)pc_shared.L;
-            override_params(pl, m, ml, L);
-            override_params(pcl, m, ml, L);
-        }
-
-        float dist = 0.0f;
-        bool done;
-        Env<K>::step(s, act, pl, dist, done);
-        // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
-        float r = -dist;
-        if (done) {
-            r = (sb < 0) ? 1.0f : 0.0f;
-            sb = (sb < 0) ? 0 : sb + 1;
-        }
-        // everything that does not need the reset state goes out first
         if (a.rew_out) buf_st(make_rsrc(a.rew_out), off, 0, r);
         if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, 0);
         if (track) {
@@ -786,11 +843,12 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         }
         if (done) {
             buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-            if (auto_reset) {
-                buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)(rc + 1u));
-                reset_state<K>(a.seed, env_id, rc, s);
-            }
+            if (auto_reset) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)(rc + 1u));
         }
+    }
+    if (auto_reset)   // wave-uniform; every lane takes part
+        reset_state_wave<K>(a.seed, a.env_base + (uint64_t)(gi - (threadIdx.x & 63u)), rc, done && valid, s);
+    if (valid) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
         if (a.obs_out) {
@@ -804,9 +862,11 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
                 for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
             }
         }
-        if constexpr (CTRL) {   // control() of the state this launch leaves behind
-            float a2[NA];
-            env_control<K>(s, pcl, a2);
+    }
+    if constexpr (CTRL) {   // control() of the state this launch leaves behind
+        float a2[NA];
+        env_control<K>(s, pcl, a2);
+        if (valid) {
             if (aos) {
                 float *dst = a.ctrl_out + (int64_t)li * NA;
 #pragma unroll

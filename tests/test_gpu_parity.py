@@ -125,6 +125,39 @@ def test_reset_streams_bit_exact_and_shard_invariant(G, kind):
         e.close()
 
 
+@pytest.mark.parametrize("frac", [1.0, 0.3, 0.02])
+@pytest.mark.parametrize("n", [1, 3, 64, 200, 4099])
+@pytest.mark.parametrize("kind", KINDS)
+def test_single_step_auto_reset_any_number_of_terminations(G, kind, n, frac):
+    """The single-step kernel draws reset states cooperatively (four lanes per terminating env, 16 terminations per
+    Philox pass): every count of terminating lanes per wavefront - none, one, more than 16, all 64, ragged last
+    wavefront, a one-env batch - must give the spec'd reset state bit for bit, twice in a row."""
+    seed = 31
+    rng = np.random.RandomState(n)
+    env = G.BatchedQuadrotor(kind, n, seed=seed, env_id_base=5000, auto_reset=True, track_episodes=True)
+    s = env.get_state() * 0.2
+    kill = rng.uniform(size=n) < frac
+    s[kill] += 40.0                              # every component far outside the limits: these envs terminate
+    lo, hi = BOX[kind]
+    for rep in range(2):
+        env.set_state(s)
+        rc = env.get_reset_counts()
+        a = rng.uniform(lo, hi, (n, NA[kind])).astype(np.float32) * 0.1
+        obs, rew, done = env.step(a)
+        o2, r, d, _ = O.batch_step(kind, s.astype(np.float64), a.astype(np.float64))
+        assert np.array_equal(d, kill), "test set-up: exactly the chosen envs terminate"
+        assert np.array_equal(done, d)
+        if (~kill).any():
+            assert scaled_err(obs[~kill], o2[~kill]).max() <= TOL
+        if kill.any():
+            assert np.array_equal(obs[kill], O.reset_states(kind, seed, 5000 + np.nonzero(kill)[0], rc[kill]))
+        assert np.array_equal(env.get_reset_counts(), rc + kill.astype(np.uint32))
+        assert np.array_equal(env.get_state(), obs)
+    tot = env.episode_totals()
+    assert tot["episodes"] == 2 * int(kill.sum()) and tot["length_sum"] == 2 * int(kill.sum())
+    env.close()
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_lifetime_terminal_reward_once(G, kind, golden):
     """Q1 through the device path: rewards at the three terminations are 1.0, 0.0, 0.0 and

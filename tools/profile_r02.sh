@@ -1,0 +1,43 @@
+#!/bin/bash
+# rocprofv3 evidence for round 2: kernel trace + stats of the bench commands, then separate PMC passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they need 3 + 2; no --stats with --pmc).
+# Usage (via gpurun, from the repo root): bash tools/profile_r02.sh r02
+TAG=${1:-r02}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+B="python $REPO/bench.py --no-secondary --cpu-seconds 0"
+run() {  # name, rocprof args..., -- cmd
+  local name=$1; shift
+  echo "== $name"
+  timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1
+  echo "rc=$? $(grep '^{' $OUT/$name.log | tail -1 | cut -c1-200)"
+}
+# name | bench arguments
+CASES=(
+  "c2_ring|"
+  "c2_inplace|--in-place"
+  "c2_step|--mode step --steps 3000 --warmup 300"
+  "c3shard_ring|--envs-per-gpu 131072 --steps 1000 --warmup 100"
+  "c4_ring|--kind quad3d_sl --envs-per-gpu 262144 --steps 400 --warmup 50"
+)
+for c in "${CASES[@]}"; do
+  name=${c%%|*}; args=${c#*|}
+  run trace_$name --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- $B $args
+  for C in FETCH_SIZE WRITE_SIZE; do
+    # fewer launches under the counters; the warm-up still cycles the whole ring once
+    run pmc_${name}_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${name}_$C -- $B $args --steps 60 --warmup 30
+  done
+done
+# calibration of the two counters on a known byte count far beyond the Infinity Cache (16 M envs, single step)
+for C in FETCH_SIZE WRITE_SIZE; do
+  run pmc_calib_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_calib_$C -- $B --mode step --envs-per-gpu 16777216 --steps 6 --warmup 2
+done
+cd $REPO
+python tools/parse_rocprof.py $OUT > $OUT/summary.md 2>&1
+tail -80 $OUT/summary.md
+find $OUT -name "*_agent_info.csv" -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
+du -sh $OUT
