@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
     ap.add_argument("--in-place", action="store_true", help="rollout mode: rewrite ONE trajectory buffer set (cache-assisted)")
     ap.add_argument("--ring", type=int, default=0, help="rollout mode: number of trajectory buffer sets (0 = >= 5 and > 1.5 GB)")
+    ap.add_argument("--exchange-every", type=int, default=1,
+                    help="multi-rank runs: post the episode-stats all-gather after every k-th rollout launch (default 1 = every launch)")
     ap.add_argument("--action-ring", type=int, default=64, help="step mode: number of pre-generated action buffers")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
@@ -130,7 +132,7 @@ def main():
     import torch.distributed as dist
 
     import gym_reinmav_amd as g
-    from gym_reinmav_amd.distributed import EpisodeStatsExchange, all_reduce_totals
+    from gym_reinmav_amd.distributed import EpisodeStatsExchange, NativeStatsExchange, all_reduce_totals
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -170,7 +172,27 @@ def main():
         env = g.BatchedQuadrotor(kind, n, device=local_dev, seed=0, env_id_base=rank * n, auto_reset=True,
                                  track_episodes=True)
         gloo = use_dist and dist.get_backend() == "gloo"
-        exchange = EpisodeStatsExchange(n_total, "cpu" if gloo else dev) if use_dist else None
+        exchange, exchange_kind = None, None
+        if use_dist:
+            # the collective behind the C ABI (RCCL from librmav's own stream, ~15 us of host time per post); every rank must
+            # take the same path, so fall back together to the torch.distributed exchange if any rank cannot set it up
+            ok = 0
+            if not gloo and os.environ.get("RMAV_BENCH_EXCHANGE", "native") == "native":
+                try:
+                    exchange = NativeStatsExchange(env, n_total)
+                    ok = 1
+                except Exception as e:  # pragma: no cover
+                    print(f"[rank {rank}] native exchange unavailable: {e!r}", file=sys.stderr)
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                exchange_kind = "rmav_allgather_stats_post/_result (RCCL from librmav.so, own stream)"
+            else:
+                if exchange is not None:
+                    exchange.close()
+                exchange = EpisodeStatsExchange(n_total, "cpu" if gloo else dev)
+                exchange_kind = "torch.distributed all_gather_into_tensor (" + dist.get_backend() + "), second stream"
 
         # step mode: ring of pre-generated action buffers (fresh random actions every launch).  64 buffers = 67 MB at
         # 65 536 envs: like the actions a policy kernel has just written, they are still on chip (L2 / Infinity Cache)
@@ -195,11 +217,13 @@ def main():
             if mode == "rollout":
                 shp = (lambda d: (chunk, d, n)) if args.layout == "soa" else (lambda d: (chunk, n, d))
                 R = ring_size(chunk, in_place)
+                # zero-filled at set-up so that every buffer set is mapped before the warm-up (a short --warmup would
+                # otherwise first-touch part of the ring inside the timed region)
                 ring = [{
-                    "actions": torch.empty(shp(nA), dtype=torch.float32, device=dev),
-                    "obs": torch.empty(shp(nS), dtype=torch.float32, device=dev),
-                    "rew": torch.empty((chunk, n), dtype=torch.float32, device=dev),
-                    "done": torch.empty((chunk, n), dtype=torch.uint8, device=dev),
+                    "actions": torch.zeros(shp(nA), dtype=torch.float32, device=dev),
+                    "obs": torch.zeros(shp(nS), dtype=torch.float32, device=dev),
+                    "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
+                    "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev),
                 } for _ in range(R)]
                 it = [0]
 
@@ -208,7 +232,7 @@ def main():
                         env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
                                     want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
                         it[0] += 1
-                        if exchange is not None:   # the path's one exchange, once per rollout
+                        if exchange is not None and it[0] % args.exchange_every == 0:   # the path's one exchange, once per rollout
                             if gloo:
                                 eb = env.episode_buffers()
                                 exchange.post(torch.from_numpy(eb["last_return"]), torch.from_numpy(eb["last_length"]))
@@ -352,8 +376,9 @@ def main():
                 "mode": args.mode,
                 "trajectory_layout": args.layout if args.mode == "rollout" else "soa",
                 "trajectory_ring": R,
-                "parallelism": (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one RCCL all-gather of "
-                                "per-env episode stats after EVERY rollout launch, overlapped with the next launch on a second stream)")
+                "parallelism": (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one all-gather of "
+                                f"per-env episode stats after every {'rollout launch' if args.exchange_every == 1 else str(args.exchange_every) + ' rollout launches'}, overlapped with the next launch on a second stream: "
+                                f"{exchange_kind})")
                 if use_dist else "single GPU",
                 "finished_episodes": totals["episodes"],
                 "gathered_envs_with_a_finished_episode": gathered_finished,
@@ -405,6 +430,9 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["cpu_baseline_python"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    if exchange is not None and hasattr(exchange, "close"):
+        torch.cuda.synchronize()
+        exchange.close()
     env.close()
     if use_dist:
         dist.barrier()

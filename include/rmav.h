@@ -275,6 +275,13 @@ int rmav_comm_destroy(rmav_comm c);
  * recently finished episode, in global env order, on every rank.  Enqueued on the handle's stream (pack ->
  * ncclAllGather over xGMI -> unpack); does not synchronise.  Needs RMAV_F_TRACK_EPISODES. */
 int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
+/* The same exchange in two halves, so that it overlaps the next rollout: _post packs this rank's payload on the
+ * handle's stream (a stream-ordered snapshot) and runs the ncclAllGather on the communicator's OWN stream behind
+ * an event (double-buffered: two exchanges may be in flight); _result makes the handle's stream wait for the most
+ * recently posted gather and unpacks it.  rmav_allgather_stats = _post followed by _result.  ~15 us of host time
+ * per post (one launch, two event records, one RCCL enqueue). */
+int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
+int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
 /* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
  * send_out i32 [2][cmax] (DEVICE) <- bit patterns of the per-env last returns, then the last lengths, zero padded
  * from num_envs to cmax (the largest shard).  A stream-ordered snapshot in one small launch, so the next

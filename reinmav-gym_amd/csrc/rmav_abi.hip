@@ -85,6 +85,13 @@ struct rmav_comm_s {
     uint32_t magic;
     int rank, world, device;
     ncclComm_t comm;
+    // overlapped exchange: the collective runs on the communicator's own stream, double-buffered
+    hipStream_t stream;
+    hipEvent_t ready[2], done[2];
+    bool used[2];
+    int32_t *send[2], *recv[2];
+    int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
+    int posts;         // number of posts so far (buffer of post i is i & 1)
 };
 
 namespace {
@@ -536,7 +543,9 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     h->flags = flags;
     h->params = pr;
     if (hip_stream) {
-        h->stream = (hipStream_t)hip_stream;
+        // (void*)1 names the legacy default stream, whose real handle is 0: use that (some runtime entry points -
+        // hipEventRecord - do not accept the hipStreamLegacy constant)
+        h->stream = (hip_stream == (void *)1) ? nullptr : (hipStream_t)hip_stream;
         h->own_stream = false;
     } else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -662,7 +671,9 @@ int rmav_set_stream(rmav_handle h, void *hip_stream) {
         h->own_stream = false;
     }
     if (hip_stream) {
-        h->stream = (hipStream_t)hip_stream;
+        // (void*)1 names the legacy default stream, whose real handle is 0: use that (some runtime entry points -
+        // hipEventRecord - do not accept the hipStreamLegacy constant)
+        h->stream = (hip_stream == (void *)1) ? nullptr : (hipStream_t)hip_stream;
     } else {
         HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
         h->own_stream = true;
@@ -1138,15 +1149,25 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     memcpy(&uid, id, sizeof(uid));
     rmav_comm c = new (std::nothrow) rmav_comm_s();
     if (!c) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    memset(c, 0, sizeof(*c));
     c->magic = kCommMagic;
     c->rank = rank;
     c->world = world;
     c->device = device;
-    c->comm = nullptr;
     ncclResult_t r = R->CommInitRank(&c->comm, world, uid, rank);
     if (r != ncclSuccess) {
         delete c;
         return fail(RMAV_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+    }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&c->ready[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)rmav_comm_destroy(c);
+        return fail(RMAV_ERR_HIP, "stream / event creation for the communicator failed: %s", hipGetErrorString(e));
     }
     *out = c;
     return RMAV_OK;
@@ -1154,8 +1175,17 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
 
 int rmav_comm_destroy(rmav_comm c) {
     if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    DeviceGuard guard(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     RcclApi *R = rccl();
     if (R && c->comm) (void)R->CommDestroy(c->comm);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ready[k]) (void)hipEventDestroy(c->ready[k]);
+        if (c->done[k]) (void)hipEventDestroy(c->done[k]);
+        if (c->send[k]) (void)hipFree(c->send[k]);
+        if (c->recv[k]) (void)hipFree(c->recv[k]);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
     return RMAV_OK;
@@ -1172,12 +1202,12 @@ int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
     return RMAV_OK;
 }
 
-int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out) {
-    CHECK_HANDLE(h);
+namespace {
+// shard of rank c->rank out of n_total, checked against the handle
+int check_shard(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out) {
     if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
         return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
-    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
     if (c->device != h->device) return fail(RMAV_ERR_INVALID, "communicator and handle live on different devices");
     const int64_t W = c->world, base = n_total / W, rem = n_total % W;
     if (n_total <= 0 || base == 0) return fail(RMAV_ERR_INVALID, "n_total must be >= the number of ranks");
@@ -1186,21 +1216,67 @@ int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *ret
         return fail(RMAV_ERR_INVALID, "rank %d of %d must own envs [%lld, %lld) of %lld; the handle owns [%llu, %llu)", c->rank,
                     c->world, (long long)start, (long long)(start + count), (long long)n_total,
                     (unsigned long long)h->env_base, (unsigned long long)(h->env_base + (uint64_t)h->n));
+    *cmax_out = base + (rem ? 1 : 0);
+    return RMAV_OK;
+}
+}  // namespace
+
+int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
+    CHECK_HANDLE(h);
+    int64_t cmax = 0;
+    if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     RcclApi *R = rccl();
     if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
-    const int64_t cmax = base + (rem ? 1 : 0);
-    const size_t send_b = (size_t)(2 * cmax) * sizeof(int32_t), recv_b = send_b * (size_t)W;
-    if (int rc = ensure_scratch(h, send_b + recv_b + 256)) return rc;
-    int32_t *send = (int32_t *)h->scratch;
-    int32_t *recv = (int32_t *)((char *)h->scratch + ((send_b + 255) & ~(size_t)255));
+    if (cmax > c->cmax) {   // (re)allocate the two buffer pairs
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        for (int k = 0; k < 2; ++k) {
+            if (c->send[k]) (void)hipFree(c->send[k]);
+            if (c->recv[k]) (void)hipFree(c->recv[k]);
+            c->send[k] = c->recv[k] = nullptr;
+            c->used[k] = false;
+            if (hipMalloc((void **)&c->send[k], (size_t)(2 * cmax) * sizeof(int32_t)) != hipSuccess ||
+                hipMalloc((void **)&c->recv[k], (size_t)(2 * cmax) * sizeof(int32_t) * (size_t)c->world) != hipSuccess) {
+                (void)hipGetLastError();
+                c->cmax = 0;
+                return fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
+            }
+        }
+        c->cmax = cmax;
+    }
+    const int k = c->posts & 1;
+    // the gather that last used this buffer pair must have finished before the pack overwrites its send half
+    if (c->used[k]) HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float *)h->last_ret, (const int32_t *)h->last_len, count, cmax, send);
+                       (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
     HIP_TRY(hipGetLastError());
-    RCCL_TRY(R->AllGather(send, recv, (size_t)(2 * cmax), ncclInt32, c->comm, h->stream));
+    HIP_TRY(hipEventRecord(c->ready[k], h->stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
+    RCCL_TRY(R->AllGather(c->send[k], c->recv[k], (size_t)(2 * cmax), ncclInt32, c->comm, c->stream));
+    HIP_TRY(hipEventRecord(c->done[k], c->stream));
+    c->used[k] = true;
+    c->posts += 1;
+    return RMAV_OK;
+}
+
+int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out) {
+    CHECK_HANDLE(h);
+    int64_t cmax = 0;
+    if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
+    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
+    if (c->posts == 0 || cmax != c->cmax) return fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
+    const int k = (c->posts - 1) & 1;
+    HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
-                       (const int32_t *)recv, n_total, (int32_t)W, cmax, returns_out, lengths_out);
+                       (const int32_t *)c->recv[k], n_total, (int32_t)c->world, cmax, returns_out, lengths_out);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
+}
+
+int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out) {
+    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
+    if (int rc = rmav_allgather_stats_post(h, c, n_total)) return rc;
+    return rmav_allgather_stats_result(h, c, n_total, returns_out, lengths_out);
 }
 
 }  // extern "C"

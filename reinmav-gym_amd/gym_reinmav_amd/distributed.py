@@ -88,6 +88,8 @@ class EpisodeStatsExchange:
         self.recv = [torch.empty(self.world * 2 * self.cmax, dtype=torch.int32, device=self.device) for _ in range(2)]
         self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self.done_ev = [None, None]
+        self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self.on_gpu else None   # reused: no per-post allocation
+        self._done = [torch.cuda.Event(), torch.cuda.Event()] if self.on_gpu else None
         self.i = 0
         self.last = None
 
@@ -106,12 +108,12 @@ class EpisodeStatsExchange:
             s[:self.count].copy_(last_return.view(torch.int32))
             s[self.cmax:self.cmax + self.count].copy_(last_length)
         if self.on_gpu:
-            ready = torch.cuda.Event()
+            ready = self._ready[k]
             ready.record(cur)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
                 dist.all_gather_into_tensor(self.recv[k], s, group=self.group)
-                ev = torch.cuda.Event()
+                ev = self._done[k]
                 ev.record(self.comm_stream)
             self.done_ev[k] = ev
         else:
@@ -132,6 +134,53 @@ class EpisodeStatsExchange:
             rets.append(recv[r, 0, :c].view(torch.float32))
             lens.append(recv[r, 1, :c])
         return torch.cat(rets), torch.cat(lens)
+
+
+class NativeStatsExchange:
+    """The same overlapped exchange with the collective issued by ``librmav.so`` itself (``rmav_comm_*`` +
+    ``rmav_allgather_stats_post / _result``: RCCL ``ncclAllGather`` on the communicator's own HIP stream, double
+    buffered).  ``torch.distributed`` only carries the 128-byte RCCL unique id from rank 0 to the others.  About
+    15 us of host time per post against ~100 us for ``all_gather_into_tensor`` behind Python, which matters when one
+    exchange follows every ~100 us rollout launch."""
+
+    def __init__(self, env, n_total: int, group=None):
+        import ctypes as C
+
+        from . import _abi as A
+
+        self._A, self._C, self.env = A, C, env
+        self.n_total, self.group = int(n_total), group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        L = A.lib()
+        dev = torch.device("cuda", env.device)
+        on_gpu = dist.get_backend(group) == "nccl"
+        uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_char * A.COMM_ID_BYTES)()
+            A.check(L.rmav_comm_unique_id(buf))
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        uid = uid.to(dev) if on_gpu else uid
+        dist.broadcast(uid, src=0, group=group)
+        raw = bytes(uid.cpu().numpy().tobytes())
+        self._comm = C.c_void_p()
+        A.check(L.rmav_comm_create(C.byref(self._comm), raw, self.rank, self.world, env.device))
+        self.ret = torch.empty(self.n_total, dtype=torch.float32, device=dev)
+        self.len = torch.empty(self.n_total, dtype=torch.int32, device=dev)
+
+    def post(self, env=None, **_):
+        e = env if env is not None else self.env
+        self._A.check(self._A.lib().rmav_allgather_stats_post(e._h, self._comm, self.n_total))
+
+    def result(self):
+        C = self._C
+        self._A.check(self._A.lib().rmav_allgather_stats_result(self.env._h, self._comm, self.n_total,
+                                                                 C.c_void_p(self.ret.data_ptr()), C.c_void_p(self.len.data_ptr())))
+        return self.ret, self.len
+
+    def close(self):
+        if self._comm:
+            self._A.lib().rmav_comm_destroy(self._comm)
+            self._comm = None
 
 
 def all_reduce_totals(totals: dict, device=None, group=None) -> dict:

@@ -80,3 +80,14 @@ def test_bench_under_torchrun_single_rank_rccl(built):
     j = _line(r.stdout)
     assert j["n_gpus"] == 1 and j["config"]["gathered_envs_with_a_finished_episode"] > 0
     assert 0.0 < j["roofline"]["frac"] <= 1.0
+    assert "rmav_allgather_stats_post" in j["config"]["parallelism"], j["config"]["parallelism"]
+    # the torch.distributed exchange (the fallback) gives the same statistics
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port + 1), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "40",
+                         "--warmup", "10", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=850, cwd=ROOT,
+                        env=dict(os.environ, RMAV_BENCH_EXCHANGE="torch"))
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    j2 = _line(r2.stdout)
+    assert "all_gather_into_tensor" in j2["config"]["parallelism"]
+    assert j2["config"]["gathered_envs_with_a_finished_episode"] == j["config"]["gathered_envs_with_a_finished_episode"]
+    assert j2["config"]["finished_episodes"] == j["config"]["finished_episodes"]
