@@ -131,8 +131,8 @@ inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
 int block_size() {
     static int b = [] {
         const char *e = getenv("RMAV_BLOCK");
-        int v = e ? atoi(e) : kBlock;
-        return (v == 64 || v == 128 || v == 256) ? v : kBlock;
+        int v = e ? atoi(e) : 256;
+        return (v == 64 || v == 128 || v == 256 || ((v == 512 || v == 1024) && v <= kBlock)) ? v : (kBlock > 256 ? 256 : kBlock);
     }();
     return b;
 }
@@ -213,14 +213,22 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
     return bytes <= 192.0e6 ? ST_WRITE_THROUGH : ST_STREAM;
 }
 
-// Two-wavefront (integrator + memory wavefront) kernel or one wavefront per 64 envs?  The second wavefront pays while
-// the batch leaves the SIMDs under-occupied (one wavefront per SIMD = 65 536 envs) and costs occupancy and LDS beyond
-// that.  Crossover batch sizes per kind and action source, measured on cold trajectory buffers in steps of 16 384 envs
-// with four pairs per workgroup (profiles/r02/split_crossover.md; the two-wavefront kernel is used BELOW the entry,
-// which sits halfway between its last win and its first loss):
-//                                            quad2d   quad2d_sl  quad3d  quad3d_sl
-constexpr int64_t kSplitBelowRandom[4]     = {139264,  122880,    122880, 73728};   // helper draws the actions and drains
-constexpr int64_t kSplitBelowController[4] = {106496,  73728,     106496, 73728};   // helper only drains
+// Two-wavefront (integrator + memory wavefront) kernel or one wavefront per 64 envs?  Measured on cold trajectory
+// buffers (profiles/r02/split_autog.md: every kind, both in-kernel action sources, 16 384 .. 163 840 envs): the
+// two-wavefront kernel wins or ties whenever the whole batch fits ONE workgroup per CU - ceil(N / 16 384) pairs per
+// workgroup, 256 workgroups - and loses as soon as it does not (a second round of workgroups, or pairs capped by the
+// 1024-thread / 160 KiB-LDS limits).  So the rule is capacity, not a tuned constant: two wavefronts iff
+// N <= 16 384 x (pairs that fit one workgroup for this kind and action source).
+template <int K, bool DRAWS> constexpr int split_pairs_max() {
+    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * SplitTile<Dims<K>::NS, Dims<K>::NA, DRAWS>::WORDS));
+    return by_lds < kSplitGroupMax ? by_lds : kSplitGroupMax;
+}
+constexpr int kSplitPairsRandom[4] = {split_pairs_max<QUAD2D, true>(), split_pairs_max<QUAD2D_SL, true>(),
+                                      split_pairs_max<QUAD3D, true>(), split_pairs_max<QUAD3D_SL, true>()};
+constexpr int kSplitPairsController[4] = {split_pairs_max<QUAD2D, false>(), split_pairs_max<QUAD2D_SL, false>(),
+                                          split_pairs_max<QUAD3D, false>(), split_pairs_max<QUAD3D_SL, false>()};
+constexpr int64_t kEnvsPerCuSlot = 16384;   // 256 CUs x 64 envs: one pair per CU
+
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     const typename Env<K>::P p = derive_env<K>(h->params);
@@ -229,11 +237,21 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
-    if constexpr (is_split(MODE)) {   // (integrator, memory wavefront) pairs, kSplitGroup of them per workgroup
+    if constexpr (is_split(MODE)) {
+        // (integrator, memory wavefront) pairs: as many per workgroup as make ONE workgroup per CU (256 workgroups),
+        // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_SPLIT_GROUP=1..8 overrides.
         using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, MODE == ACT_RANDOM_SPLIT>;
-        constexpr int64_t per_wg = 64 * kSplitGroup;
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * kSplitGroup),
-                           sizeof(float) * Tile::WORDS * kSplitGroup, h->stream, a, p, pc);
+        static const int forced = [] {
+            const char *e = getenv("RMAV_SPLIT_GROUP");
+            return e ? atoi(e) : 0;
+        }();
+        constexpr int g_max = split_pairs_max<K, MODE == ACT_RANDOM_SPLIT>();
+        int g = (forced >= 1 && forced <= kSplitGroupMax) ? forced : (int)((h->n + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
+        if (g < 1) g = 1;
+        if (g > g_max) g = g_max;
+        const int64_t per_wg = 64 * g;
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g),
+                           sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     }
@@ -241,7 +259,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     return RMAV_OK;
 }
 
-// RMAV_SPLIT=0|1 overrides the table.
+// RMAV_SPLIT=0|1 overrides the rule.
 bool use_split(rmav_handle h, const RolloutArgs &a, bool draws = true) {
     static const int forced = [] {
         const char *e = getenv("RMAV_SPLIT");
@@ -249,7 +267,7 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws = true) {
     }();
     if (a.n_steps < 8 || h->kind > RMAV_QUAD3D_SL) return false;
     if (forced == 0 || forced == 1) return forced == 1;
-    return h->n < (draws ? kSplitBelowRandom : kSplitBelowController)[h->kind];
+    return h->n <= kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
 }
 
 template <int K, int MODE>

@@ -44,17 +44,16 @@ constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BU
 #define RMAV_SPLIT_CHUNK 2
 #endif
 constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
-// Split modes: (integrator, memory wavefront) pairs per workgroup.  The pairs of one workgroup own ADJACENT 64-env
-// groups and run on one CU, so its memory wavefronts store adjacent 256-byte segments of every trajectory column
-// (the store-only microbenchmark tools/micro/store_patterns.hip absorbs 1 KiB-per-CU segments 6 % faster than
-// 256-byte ones at 65 536 envs on cold buffers).  Measured on cold trajectory buffers, 64-step launches, 1 -> 4 pairs
-// (profiles/r02/split_group_ab.md): quadrotor3d 46.2 -> 45.5 us at 65 536 envs, slung load 74.3 -> 73.4, 2-D 45.5 ->
-// 43.6, 2-D slung load 67.8 -> 65.1; at 131 072 envs 3-D slung load 180 -> 148 us.  2 pairs are slower than either
-// (both integrators land on one pair of SIMDs).
-#ifndef RMAV_SPLIT_GROUP
-#define RMAV_SPLIT_GROUP 4
-#endif
-constexpr int kSplitGroup = RMAV_SPLIT_GROUP;
+// Split modes: (integrator, memory wavefront) pairs per workgroup - a launch parameter (blockDim.x / 128, 1 .. 8).
+// The pairs of one workgroup own ADJACENT 64-env groups and run on one CU, so its memory wavefronts store adjacent
+// 256-byte segments of every trajectory column (the store-only microbenchmark tools/micro/store_patterns.hip absorbs
+// 1 KiB-per-CU segments 6 % faster than 256-byte ones at 65 536 envs on cold buffers, and is at its fastest with
+// 128-256 large workgroups).  Measured on cold trajectory buffers, 64-step launches (profiles/r02/split_group_ab.md,
+// wg_scan.md): 1 -> 4 pairs at 65 536 envs: quadrotor3d 46.2 -> 45.5 us, slung load 74.3 -> 73.4, 2-D 45.5 -> 43.6,
+// 2-D slung load 67.8 -> 65.1; 4 -> 8 pairs at 131 072 envs: quadrotor3d 102 -> 90 us (the one-wavefront kernel: 101),
+// but 45 -> 64 us at 65 536 envs, where 8 pairs leave half of the CUs empty and put two integrators on every SIMD.
+// The sweet spot is ONE workgroup per CU: the host launches ceil(N / 16 384) pairs per workgroup (256 workgroups).
+constexpr int kSplitGroupMax = 8;   // 1024 threads
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int A_HALF = DRAWS ? kSplitChunk * NA * 64 : 0, A_WORDS = 2 * A_HALF;
     // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
@@ -66,7 +65,10 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
-constexpr int kBlock = 256;  // upper bound (launch bounds); the launch may use 64/128/256
+#ifndef RMAV_KBLOCK
+#define RMAV_KBLOCK 256
+#endif
+constexpr int kBlock = RMAV_KBLOCK;  // upper bound (launch bounds); the launch may use 64/128/256 (.. RMAV_KBLOCK)
 
 struct Totals {
     unsigned long long episodes;
@@ -166,18 +168,21 @@ __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t sof
 }
 
 template <int K, int MODE, int ST = ST_DEFAULT>
-__global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroup : kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
+__global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;
     // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
     constexpr bool SPLIT = is_split(MODE), DRAWS = (MODE == ACT_RANDOM_SPLIT);
-    const uint32_t gi = SPLIT ? blockIdx.x * (64u * kSplitGroup) + (threadIdx.x & (64u * kSplitGroup - 1u))
-                              : blockIdx.x * blockDim.x + threadIdx.x;
+    // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
+    const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
+    const bool split_helper = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
+    const uint32_t split_local = threadIdx.x - (split_helper ? 64u * split_g : 0u);
+    const uint32_t gi = SPLIT ? blockIdx.x * (64u * split_g) + split_local : blockIdx.x * blockDim.x + threadIdx.x;
     // SPLIT: this pair's hand-over tiles
     [[maybe_unused]] float *lds_p = lds_w;
-    if constexpr (SPLIT && kSplitGroup > 1)
-        lds_p = lds_w + __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) % kSplitGroup) * SplitTile<NS, NA, DRAWS>::WORDS;
+    if constexpr (SPLIT)
+        lds_p = lds_w + (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * SplitTile<NS, NA, DRAWS>::WORDS;
     const int64_t n = a.n;
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroup : kBlock) void k
     // hands the action over with its other outputs; the helper only drains.
     if constexpr (SPLIT) {
         using ST_ = SplitTile<NS, NA, DRAWS>;
-        if ((uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= (uint32_t)kSplitGroup) {
+        if (split_helper) {
             const uint64_t env_id = a.env_base + (uint64_t)li;
             const uint32_t lane = threadIdx.x & 63u;
             const int32_t T = a.n_steps;

@@ -318,7 +318,16 @@ int main(int argc, char **argv) {
         row<1, 1>(st, ring, n, 0, T, 256);
         row<4, 1>(st, ring, n, 0, T, 256);
         }
-        if (getenv("SIM")) {
+        if (getenv("V4")) {   // grid-size scan of the sliced write-through kernel: which workgroup counts are fast?
+            for (uint32_t wgs : {64u, 96u, 112u, 120u, 128u, 136u, 144u, 160u, 192u, 224u, 256u, 384u, 512u})
+                row_sliced<1>(st, ring, n, T, wgs * 256u, 256);
+            for (uint32_t wgs : {256u, 384u, 512u, 768u, 1024u})
+                row_sliced<1>(st, ring, n, T, wgs * 64u, 64);
+            for (uint32_t wgs : {128u, 192u, 256u, 512u})
+                row_sliced<1>(st, ring, n, T, wgs * 128u, 128);
+            for (uint32_t wgs : {32u, 48u, 64u, 96u, 128u})
+                row_sliced<1>(st, ring, n, T, wgs * 512u, 512);
+        } else if (getenv("SIM")) {
             for (int chain : {0, 230, 330}) {
                 for (int block : {64, 256}) {
                     row_sim<1, true>(st, ring, n, T, chain, n, block);          // one env per lane, full grid (today's shape)
