@@ -90,6 +90,7 @@ struct rmav_comm_s {
     hipEvent_t ready[2], done[2];
     bool used[2];
     int32_t *send[2], *recv[2];
+    uint32_t *flag;    // signal word (hipMallocSignalMemory): the compute stream publishes post numbers, the comm stream waits
     int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
     int posts;         // number of posts so far (buffer of post i is i & 1)
 };
@@ -1179,13 +1180,34 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
-        e = hipEventCreateWithFlags(&c->ready[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming);
+        // device-scope release: these events only order streams of this GPU (RMAV_DBG_EVENT_FLAGS overrides, diagnostic)
+        static const unsigned evf = [] {
+            const char *e2 = getenv("RMAV_DBG_EVENT_FLAGS");
+            return e2 ? (unsigned)strtoul(e2, nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
+        }();
+        e = hipEventCreateWithFlags(&c->ready[k], evf);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[k], evf);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)rmav_comm_destroy(c);
         return fail(RMAV_ERR_HIP, "stream / event creation for the communicator failed: %s", hipGetErrorString(e));
+    }
+    // Hand-over from the compute stream to the communicator's stream without an event: hipEventRecord puts a barrier
+    // packet into the COMPUTE stream (~8 us in front of the next rollout launch, measured); a one-thread kernel that
+    // publishes the post number in a signal word, and hipStreamWaitValue32 on the communicator's stream, cost the
+    // compute stream one tiny launch.  Falls back to the event when the device cannot wait on memory.
+    int can_wait = 0;
+    (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
+    const char *e2 = getenv("RMAV_EXCHANGE_EVENTS");   // =1: hand over with events (diagnostic A/B)
+    const bool no_signal = e2 && atoi(e2) == 1;
+    if (can_wait && !no_signal) {
+        if (hipExtMallocWithFlags((void **)&c->flag, 8, hipMallocSignalMemory) != hipSuccess) {
+            (void)hipGetLastError();
+            c->flag = nullptr;
+        } else {
+            (void)hipMemset(c->flag, 0, 8);
+        }
     }
     *out = c;
     return RMAV_OK;
@@ -1203,6 +1225,7 @@ int rmav_comm_destroy(rmav_comm c) {
         if (c->send[k]) (void)hipFree(c->send[k]);
         if (c->recv[k]) (void)hipFree(c->recv[k]);
     }
+    if (c->flag) (void)hipFree(c->flag);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -1264,12 +1287,28 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     }
     const int k = c->posts & 1;
     // the gather that last used this buffer pair must have finished before the pack overwrites its send half
-    if (c->used[k]) HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
+    // (normally it finished long ago - the host sees that and nothing is inserted into the compute stream)
+    if (c->used[k] && hipEventQuery(c->done[k]) != hipSuccess) {
+        (void)hipGetLastError();
+        HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
+    }
     hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
                        (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ready[k], h->stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
+    if (c->flag) {
+        const uint32_t seq = (uint32_t)(c->posts + 1);
+        hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, h->stream, c->flag, seq);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamWaitValue32(c->stream, c->flag, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+    } else {
+        HIP_TRY(hipEventRecord(c->ready[k], h->stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
+    }
+    static const int dbg = [] { const char *e = getenv("RMAV_DBG_EXCHANGE"); return e ? atoi(e) : 0; }();
+    if (dbg == 1) {   // diagnostic: no collective at all
+    } else if (dbg == 2) {   // diagnostic: a plain copy instead of the RCCL kernel (single rank only)
+        HIP_TRY(hipMemcpyAsync(c->recv[k], c->send[k], (size_t)(2 * cmax) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else
     RCCL_TRY(R->AllGather(c->send[k], c->recv[k], (size_t)(2 * cmax), ncclInt32, c->comm, c->stream));
     HIP_TRY(hipEventRecord(c->done[k], c->stream));
     c->used[k] = true;

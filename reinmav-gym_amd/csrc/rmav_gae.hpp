@@ -139,6 +139,11 @@ __global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ la
     send[i] = i < count ? __float_as_int(last_ret[i]) : 0;
     send[cmax + i] = i < count ? last_len[i] : 0;
 }
+// one thread: publish `seq` in a signal word another HIP stream waits on with hipStreamWaitValue32 (the kernel
+// boundary in front of this launch has released the payload)
+__global__ void k_signal(uint32_t *flag, uint32_t seq) {
+    __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // recv = [world][2][cmax] -> returns_out / lengths_out [n_total] in global env order (rank r owns
 // base + (r < rem) envs starting at r * base + min(r, rem))
 __global__ __launch_bounds__(256) void k_unpack_stats(const int32_t *__restrict__ recv, int64_t n_total, int32_t world,

@@ -11,24 +11,28 @@ st = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(st):
     env = g.BatchedQuadrotor("quad3d", n, seed=0)
     bufs = [env.rollout(T, mode="random", want=("actions", "obs", "rew", "done"), device_out=True) for _ in range(4)]
-    uid = (C.c_char * A.COMM_ID_BYTES)(); A.check(L.rmav_comm_unique_id(uid))
-    comm = C.c_void_p(); A.check(L.rmav_comm_create(C.byref(comm), uid, 0, 1, 0))
+    comms = {}
+    for name, ev in (("signal", "0"), ("events", "1")):
+        os.environ["RMAV_EXCHANGE_EVENTS"] = ev
+        uid = (C.c_char * A.COMM_ID_BYTES)(); A.check(L.rmav_comm_unique_id(uid))
+        comms[name] = C.c_void_p(); A.check(L.rmav_comm_create(C.byref(comms[name]), uid, 0, 1, 0))
+    comm = comms["signal"]
     send = torch.zeros(2 * n, dtype=torch.int32, device=dev)
 
     def loop(kind):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(K):
             env.rollout(T, mode="random", want=("actions", "obs", "rew", "done"), device_out=True, out=bufs[i % 4])
-            if kind == "post":
-                A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+            if kind.startswith("post"):
+                A.check(L.rmav_allgather_stats_post(env._h, comms[kind[5:]], n))
             elif kind == "pack":
                 env.pack_stats(send)
         t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
         return (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6
-    for kind in ("none", "pack", "post", "none", "pack", "post"):
+    for kind in ("none", "pack", "post_signal", "post_events") * 4:
         loop(kind)
         h, w = loop(kind)
-        print(f"{kind:5s}: host enqueue {h:7.1f} us/iter, wall {w:7.1f} us/iter", flush=True)
+        print(f"{kind:12s}: host enqueue {h:7.1f} us/iter, wall {w:7.1f} us/iter", flush=True)
     # host cost of the post alone
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for i in range(200): A.check(L.rmav_allgather_stats_post(env._h, comm, n))
