@@ -92,6 +92,7 @@ def learn(env_id, num_env, seed, total_timesteps, reward_scale=1.0, actor="fp32"
     if load_path:
         pol.load_state_dict(torch.load(load_path, map_location=f"cuda:{device}"))
     sync_parameters(pol)
+    torch.manual_seed((seed or 0) + rank)   # the torch actor's exploration noise must differ between env shards
     if actor == "torch":
         ro = RolloutCollector(env, pol, nsteps, graph=True)
     else:
