@@ -521,11 +521,11 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
 
     out = {"workload": f"{ENV_ID[kind]}, {n} envs x {T}-step rollouts, 2x64 tanh MLP policy + value net in-kernel, "
                        "trajectory + logp + values written to HBM; then rmav_gae over the [T][N] result"}
-    for bf16 in (False, True):
+    for actor in ("fp32_valu", "fp32_mfma", "bf16_mfma"):
         torch.manual_seed(0)
         env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
         pol = MlpPolicy(env.nS, env.nA).to(dev)
-        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=bf16)
+        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=(actor == "bf16_mfma"), f32_mfma=(actor == "fp32_mfma"))
         adv, ret = torch.empty_like(ro.rew), torch.empty_like(ro.rew)
         sums = torch.zeros(2, dtype=torch.float64, device=dev)
         for _ in range(5):
@@ -541,7 +541,7 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
         e2.record()
         torch.cuda.synchronize()
         ms_ro, ms_gae = e0.elapsed_time(e1) / iters, e1.elapsed_time(e2) / iters
-        out["bf16_mfma" if bf16 else "fp32"] = {"ms_per_rollout_incl_weight_pack": ms_ro, "env_steps_per_s": n * T / (ms_ro * 1e-3),
+        out[actor] = {"ms_per_rollout_incl_weight_pack": ms_ro, "env_steps_per_s": n * T / (ms_ro * 1e-3),
                                                 "gae_ms": ms_gae, "gae_GBps": 17.0 * n * T / (ms_gae * 1e-3) / 1e9}
         env.close()
     return out

@@ -125,7 +125,8 @@ int check_params(const rmav_params &q) {
     return RMAV_OK;
 }
 
-inline size_t n_waves(int64_t n) { return (size_t)((n + 63) / 64); }
+// slots of the per-wavefront episode totals: one per 32 envs (the fp32-MFMA policy mode runs 32 envs per wavefront)
+inline size_t n_total_slots(int64_t n) { return (size_t)((n + 31) / 32); }
 
 // Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
 
@@ -236,6 +237,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
     const ParamsT<double> pc = derive<double>(h->params);
     const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
+                       : (MODE == ACT_POLICY_F32M) ? sizeof(float) * Mfma32Layout::TOTAL
                        : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
                                                    : 0;
     if constexpr (is_split(MODE)) {
@@ -253,6 +255,10 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
         const int64_t per_wg = 64 * g;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g),
                            sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
+    } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
+        const int64_t per_wg = block_size() / 2;
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size()), lds,
+                           h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
     }
@@ -274,7 +280,7 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws = true) {
 template <int K, int MODE>
 int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     // the policy modes are compute-bound: one instantiation is enough there
-    if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
+    if constexpr (is_policy(MODE)) {
         return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
     } else {
         if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER) && K != REINMAV) {
@@ -304,6 +310,7 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     case RMAV_ACT_POLICY: return launch_rollout_km<K, ACT_POLICY>(h, a);
     case RMAV_ACT_POLICY_BF16: return launch_rollout_km<K, ACT_POLICY_BF16>(h, a);
     case ACT_BUFFER_CTRL: return launch_rollout_kms<K, ACT_BUFFER_CTRL, ST_DEFAULT>(h, a);   // internal (rmav_step_control)
+    case ACT_POLICY_F32M: return launch_rollout_km<K, ACT_POLICY_F32M>(h, a);
     }
     return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
@@ -587,7 +594,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         const size_t o_state = off; off += up(n * nS * sizeof(float));
         const size_t o_sbd = off; off += up(n * sizeof(int32_t));
         const size_t o_rc = off; off += up(n * sizeof(uint32_t));
-        const size_t o_tot = off; off += up(n_waves(n_envs) * sizeof(Totals));
+        const size_t o_tot = off; off += up(n_total_slots(n_envs) * sizeof(Totals));
         const size_t o_time = off; off += (kind == RMAV_REINMAV) ? up(n * sizeof(double)) : 0;
         const size_t o_er = off; off += tr ? up(n * sizeof(float)) : 0;
         const size_t o_lr = off; off += tr ? up(n * sizeof(float)) : 0;
@@ -614,7 +621,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     }
     hipError_t e = hipMemsetAsync(h->sbd, 0xFF, n * sizeof(int32_t), h->stream);  // -1 = None
     if (e == hipSuccess) e = hipMemsetAsync(h->reset_cnt, 0, n * sizeof(uint32_t), h->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, n_waves(n_envs) * sizeof(Totals), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, n_total_slots(n_envs) * sizeof(Totals), h->stream);
     if (e == hipSuccess && (flags & RMAV_F_TRACK_EPISODES)) {
         e = hipMemsetAsync(h->ep_ret, 0, n * sizeof(float), h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->last_ret, 0, n * sizeof(float), h->stream);
@@ -888,13 +895,14 @@ int64_t rmav_policy_weight_count(int kind) {
 }
 
 int64_t rmav_policy_weight_count_bf16(void) { return MfmaLayout::TOTAL; }
+int64_t rmav_policy_weight_count_f32_mfma(void) { return Mfma32Layout::TOTAL; }
 
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision) {
     CHECK_HANDLE(h);
-    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA)
-        return fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32 or RMAV_POLICY_BF16_MFMA");
+    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA && precision != RMAV_POLICY_FP32_MFMA)
+        return fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32, RMAV_POLICY_BF16_MFMA or RMAV_POLICY_FP32_MFMA");
     if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (!weights || !logp_out || !value_out)
         return fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
@@ -909,7 +917,8 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
     a.policy_w = weights;
     a.logp_out = logp_out;
     a.val_out = value_out;
-    if (int rc = launch_rollout(h, precision == RMAV_POLICY_FP32 ? RMAV_ACT_POLICY : RMAV_ACT_POLICY_BF16, a)) return rc;
+    const int kmode = precision == RMAV_POLICY_FP32 ? (int)RMAV_ACT_POLICY : precision == RMAV_POLICY_BF16_MFMA ? (int)RMAV_ACT_POLICY_BF16 : (int)ACT_POLICY_F32M;
+    if (int rc = launch_rollout(h, kmode, a)) return rc;
     h->t += (uint64_t)n_steps;
     return RMAV_OK;
 }
@@ -1027,7 +1036,7 @@ int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear) {
     if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
         return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
-    const size_t nw = n_waves(h->n);
+    const size_t nw = n_total_slots(h->n);
     Totals *host = new (std::nothrow) Totals[nw];
     if (!host) return fail(RMAV_ERR_ALLOC, "host allocation failed");
     hipError_t e = hipMemcpyAsync(host, h->totals, nw * sizeof(Totals), hipMemcpyDeviceToHost, h->stream);

@@ -27,6 +27,7 @@
 #include "rmav_math.hpp"
 #include "rmav_policy.hpp"
 #include "rmav_policy_mfma.hpp"
+#include "rmav_policy_mfma32.hpp"
 
 namespace rmav {
 
@@ -35,7 +36,11 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
               ACT_RANDOM_SPLIT = 5, ACT_CONTROLLER_SPLIT = 6,
               // internal: ACT_BUFFER, and the launch ends by evaluating control() on the state it leaves behind
               // (rmav_step_control: the gym-shaped single env gets step()'s outputs and the NEXT control() in one launch)
-              ACT_BUFFER_CTRL = 7 };
+              ACT_BUFFER_CTRL = 7,
+              // the fp32 policy on the fp32-input matrix instructions (rmav_policy_mfma32.hpp)
+              ACT_POLICY_F32M = 8 };
+constexpr bool is_mfma_policy(int mode) { return mode == ACT_POLICY_BF16 || mode == ACT_POLICY_F32M; }
+constexpr bool is_policy(int mode) { return mode == ACT_POLICY || is_mfma_policy(mode); }
 constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT; }
 constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
 // Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
@@ -184,11 +189,14 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     if constexpr (SPLIT)
         lds_p = lds_w + (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * SplitTile<NS, NA, DRAWS>::WORDS;
     const int64_t n = a.n;
+    // ACT_POLICY_F32M: 32 envs per wavefront, env = column n of the wavefront's tile, simulated by both half-waves
+    constexpr bool HALF = (MODE == ACT_POLICY_F32M);
     // The MFMA actor needs all 64 lanes of a wavefront to take part (lane l and lane l ^ 32 exchange state),
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
     // exactly what that env's lane does; only the episode totals must not count them.
-    const bool valid = gi < (uint64_t)n;
-    const uint32_t li = ((MODE == ACT_POLICY_BF16 || SPLIT) && !valid) ? (uint32_t)n - 1u : gi;   // local env index
+    const uint32_t ge = HALF ? ((gi >> 6) << 5) + (gi & 31u) : gi;                      // env this lane works on
+    const bool valid = ge < (uint64_t)n;
+    const uint32_t li = ((is_mfma_policy(MODE) || SPLIT) && !valid) ? (uint32_t)n - 1u : ge;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
@@ -332,8 +340,8 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     }
 
     // ACT_POLICY: stage the policy weights into LDS once per launch (every thread of the block helps)
-    if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
-        constexpr int NW4 = (MODE == ACT_POLICY ? PolicyLayout<NS>::TOTAL : MfmaLayout::TOTAL) / 4;
+    if constexpr (is_policy(MODE)) {
+        constexpr int NW4 = (MODE == ACT_POLICY ? PolicyLayout<NS>::TOTAL : MODE == ACT_POLICY_F32M ? Mfma32Layout::TOTAL : MfmaLayout::TOTAL) / 4;
         const float4 *src = reinterpret_cast<const float4 *>(a.policy_w);
         float4 *dst = reinterpret_cast<float4 *>(lds_w);
         for (int q = threadIdx.x; q < NW4; q += blockDim.x) dst[q] = src[q];
@@ -428,11 +436,11 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
         float *val_out = a.val_out;
         float pol_std[4] = {0.f, 0.f, 0.f, 0.f};
         float pol_logp0 = 0.0f;   // - sum(logstd) - NA/2 * ln(2 pi)
-        if constexpr (MODE == ACT_POLICY || MODE == ACT_POLICY_BF16) {
+        if constexpr (is_policy(MODE)) {
             float sl = 0.0f;
 #pragma unroll
             for (int c = 0; c < NA; ++c) {
-                const float ls = lds_w[(MODE == ACT_POLICY ? PolicyLayout<NS>::LOGSTD : MfmaLayout::LOGSTD) + c];
+                const float ls = lds_w[(MODE == ACT_POLICY ? PolicyLayout<NS>::LOGSTD : MODE == ACT_POLICY_F32M ? Mfma32Layout::LOGSTD : MfmaLayout::LOGSTD) + c];
                 pol_std[c] = expf(ls);
                 sl += ls;
             }
@@ -456,11 +464,12 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
-            if constexpr (MODE == ACT_POLICY_BF16) {
+            if constexpr (is_mfma_policy(MODE)) {
                 float x[16], mean[4], val0, z[4];
 #pragma unroll
                 for (int c = 0; c < 16; ++c) x[c] = (c < NS) ? s[c] : 0.0f;
-                policy_forward_mfma(x, mean, val0);
+                if constexpr (MODE == ACT_POLICY_BF16) policy_forward_mfma(x, mean, val0);
+                else policy_forward_mfma32<NS>(x, mean, val0);
                 gaussian4(a.seed, env_id, a.t0 + (uint64_t)k, z);
                 float q = 0.0f;
 #pragma unroll
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
                 if (done) {
                     buf_st(make_rsrc(a.last_ret), off, 0, er);
                     buf_st_i32(make_rsrc(a.last_len), off, 0, el);
-                    if (valid) {
+                    if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
                         fin_n += 1;
                         fin_len += (unsigned int)el;
                         fin_ret += er;
@@ -643,11 +652,12 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
         }
         if constexpr (SPLIT) __syncthreads();   // B(nc): the last chunk's outputs are in LDS
 
-        if constexpr (MODE == ACT_POLICY_BF16) {   // bootstrap value of the state the rollout ends in
+        if constexpr (is_mfma_policy(MODE)) {   // bootstrap value of the state the rollout ends in
             float x[16], mean[4], val0;
 #pragma unroll
             for (int c = 0; c < 16; ++c) x[c] = (c < NS) ? s[c] : 0.0f;
-            policy_forward_mfma(x, mean, val0);
+            if constexpr (MODE == ACT_POLICY_BF16) policy_forward_mfma(x, mean, val0);
+            else policy_forward_mfma32<NS>(x, mean, val0);
             buf_st(make_rsrc(val_out), off, 0, val0);
         }
         if constexpr (MODE == ACT_POLICY) {   // bootstrap value of the state the rollout ends in

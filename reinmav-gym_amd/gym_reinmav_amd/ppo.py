@@ -156,13 +156,14 @@ class _PolicyPacker:
     built once (NumPy, host) and every repack is: one ``cat`` of the parameters, one gather, and for the
     bf16 fragments one dtype conversion - a handful of launches, cheap enough to run before every rollout."""
 
-    def __init__(self, policy: MlpPolicy, n_obs: int, bf16_mfma: bool):
+    def __init__(self, policy: MlpPolicy, n_obs: int, bf16_mfma: bool, f32_mfma: bool = False):
         import numpy as np
 
         H = policy.pi[0].out_features
         assert H == 64 and policy.pi[1].in_features == 64, "the in-kernel policy is the 2 x 64 baselines mlp"
         assert n_obs <= 16
-        self.policy, self.bf16 = policy, bool(bf16_mfma)
+        self.policy, self.bf16, self.f32m = policy, bool(bf16_mfma), bool(f32_mfma)
+        assert not (self.bf16 and self.f32m)
         self.params = [policy.pi[0].weight, policy.pi[0].bias, policy.pi[1].weight, policy.pi[1].bias,
                        policy.pi[2].weight, policy.pi[2].bias, policy.vf[0].weight, policy.vf[0].bias,
                        policy.vf[1].weight, policy.vf[1].bias, policy.vf[2].weight, policy.vf[2].bias, policy.logstd]
@@ -180,7 +181,27 @@ class _PolicyPacker:
             return int(offs[6 * net + 2 * layer + 1]) + r if r < p.numel() else ZERO
 
         logstd = [int(offs[12]) + c if c < n_act else ZERO for c in range(4)]
-        if not self.bf16:
+        if self.f32m:   # A operands of v_mfma_f32_32x32x2_f32 (include/rmav.h, csrc/rmav_policy_mfma32.hpp)
+            def row(r, h):
+                return (r & 3) + 8 * (r >> 2) + 4 * h
+
+            idx = []
+            for net in range(2):
+                for T in range(2):               # A1[T][sq][lane][j] = W1p[32 T + m][2 (4 sq + j) + h]
+                    for sq in range(2):
+                        idx += [W(net, 0, 32 * T + (l & 31), 2 * (4 * sq + jj) + (l >> 5)) for l in range(64) for jj in range(4)]
+                for To in range(2):              # A2[To][Tin][rq][lane][j] = W2[32 To + m][32 Tin + row(4 rq + j, h)]
+                    for Tin in range(2):
+                        for rq in range(4):
+                            idx += [W(net, 1, 32 * To + (l & 31), 32 * Tin + row(4 * rq + jj, l >> 5)) for l in range(64) for jj in range(4)]
+                for h in range(2):               # W3[h][o][16 Tin + r] = W3p[o][32 Tin + row(r, h)]
+                    for o in range(4):
+                        idx += [W(net, 2, o, 32 * Tin + row(r, h)) for Tin in range(2) for r in range(16)]
+                idx += [Bv(net, 0, jj) for jj in range(64)] + [Bv(net, 1, jj) for jj in range(64)] + [Bv(net, 2, k) for k in range(4)]
+            idx += logstd
+            self.idx_f32 = torch.tensor(idx, dtype=torch.int64, device=policy.logstd.device)
+            self.n_out = len(idx)
+        elif not self.bf16:
             nsp = (n_obs + 3) // 4 * 4
             idx = []
             for net in range(2):
@@ -217,7 +238,7 @@ class _PolicyPacker:
     def pack(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in self.params] + [torch.zeros(1, device=self.params[0].device)])
-            if not self.bf16:
+            if self.f32m or not self.bf16:
                 res = flat[self.idx_f32]
             else:
                 fr = flat[self.idx_frag].to(torch.bfloat16).view(torch.int16).view(torch.float32)   # [2 * n_frag]
@@ -235,6 +256,12 @@ def pack_policy_weights(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tenso
     return _PolicyPacker(policy, n_obs, False).pack(out)
 
 
+def pack_policy_weights_f32_mfma(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 A operands of v_mfma_f32_32x32x2_f32: per net A1 [2][2][64][4] | A2 [2][2][4][64][4] | W3 [2][4][32] |
+    b1 [64] | b2 [64] | b3 [4], then logstd [4] (include/rmav.h)."""
+    return _PolicyPacker(policy, n_obs, False, f32_mfma=True).pack(out)
+
+
 def pack_policy_weights_bf16(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """bf16 MFMA fragments: per net A1 [2][64][8] | A2 [2][4][64][8] | A3 [4][64][8] (bf16) | b1 [64] | b2 [64] |
     b3 [32] (fp32), then logstd [4]."""
@@ -246,14 +273,21 @@ class FusedPolicyCollector:
     (2 x 64 tanh MLP + value net, weights staged in LDS) is evaluated inside the rollout kernel by the lane
     that owns the env (``rmav_rollout_policy``), so nothing but the trajectory touches HBM."""
 
-    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, bf16_mfma: bool = False):
+    def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, bf16_mfma: bool = False,
+                 f32_mfma: Optional[bool] = None):
+        """Actor arithmetic: fp32 on the fp32-input matrix instructions (``v_mfma_f32_32x32x2_f32``; the default),
+        ``f32_mfma=False`` fp32 FMAs on the vector ALU (same precision class - only the summation order differs - at
+        half the speed), ``bf16_mfma=True`` bf16 operands on the matrix cores (2.5x faster again, ~1e-2 on means)."""
         import ctypes as C
+
+        if f32_mfma is None:
+            f32_mfma = not bf16_mfma
 
         from . import _abi as A
 
         assert env.auto_reset, "rollouts need VecEnv semantics (auto-reset)"
         self.env, self.policy, self.T = env, policy, int(nsteps)
-        self.bf16_mfma = bool(bf16_mfma)
+        self.bf16_mfma, self.f32_mfma = bool(bf16_mfma), bool(f32_mfma)
         self._C, self._A = C, A
         dev = torch.device("cuda", env.device)
         N, nS, nA, T = env.num_envs, env.nS, env.nA, self.T
@@ -264,10 +298,11 @@ class FusedPolicyCollector:
         self.val = torch.empty((T + 1, N), **f32)
         self.rew = torch.empty((T, N), **f32)
         self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
-        n_w = A.lib().rmav_policy_weight_count_bf16() if self.bf16_mfma else A.lib().rmav_policy_weight_count(env.kind)
+        n_w = (A.lib().rmav_policy_weight_count_bf16() if self.bf16_mfma else
+               A.lib().rmav_policy_weight_count_f32_mfma() if self.f32_mfma else A.lib().rmav_policy_weight_count(env.kind))
         self.weights = torch.empty(n_w, **f32)
         assert self.weights.data_ptr() % 16 == 0
-        self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma)
+        self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma, f32_mfma=self.f32_mfma)
         assert self._packer.n_out == n_w, (self._packer.n_out, n_w)
         self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
 
@@ -277,7 +312,7 @@ class FusedPolicyCollector:
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
         A.check(A.lib().rmav_rollout_policy(self.env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]),
                                             p(self.rew), p(self.done), p(self.logp), p(self.val),
-                                            A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32))
+                                            A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32))
         return self
 
     def roll_over(self):

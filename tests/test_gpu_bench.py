@@ -38,7 +38,8 @@ def test_bench_single_process_line(built):
     assert "error" not in om, om
     assert 0.0 < om["step"]["roofline_frac"] <= 1.0 and 0.0 < om["rollout_in_place"]["roofline_frac"] <= 1.0
     assert om["gym1"]["us_per_iteration_control_plus_step"] > 0 and om["vecenv"]["fresh_tensors_per_step"]["us_per_step"] > 0
-    assert om["policy_rollout"]["fp32"]["env_steps_per_s"] > 0 and om["policy_rollout"]["bf16_mfma"]["env_steps_per_s"] > 0
+    assert om["policy_rollout"]["fp32_mfma"]["env_steps_per_s"] > om["policy_rollout"]["fp32_valu"]["env_steps_per_s"] > 0
+    assert om["policy_rollout"]["bf16_mfma"]["env_steps_per_s"] > 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
 
 
