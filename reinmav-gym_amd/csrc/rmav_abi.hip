@@ -230,6 +230,7 @@ constexpr int kSplitPairsRandom[4] = {split_pairs_max<QUAD2D, true>(), split_pai
 constexpr int kSplitPairsController[4] = {split_pairs_max<QUAD2D, false>(), split_pairs_max<QUAD2D_SL, false>(),
                                           split_pairs_max<QUAD3D, false>(), split_pairs_max<QUAD3D_SL, false>()};
 constexpr int64_t kEnvsPerCuSlot = 16384;   // 256 CUs x 64 envs: one pair per CU
+constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches beyond the capacity: measured, see DESIGN.md
 
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
@@ -249,11 +250,12 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
             return e ? atoi(e) : 0;
         }();
         constexpr int g_max = split_pairs_max<K, MODE == ACT_RANDOM_SPLIT>();
-        int g = (forced >= 1 && forced <= kSplitGroupMax) ? forced : (int)((h->n + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
+        const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
+        int g = (forced >= 1 && forced <= kSplitGroupMax) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
         if (g < 1) g = 1;
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g),
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
                            sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
     } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
         const int64_t per_wg = block_size() / 2;
@@ -267,14 +269,27 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
 }
 
 // RMAV_SPLIT=0|1 overrides the rule.
-bool use_split(rmav_handle h, const RolloutArgs &a, bool draws = true) {
+// Batches beyond that capacity can still run on the two-wavefront kernel as a sequence of launches over balanced
+// slices of the env range, each one workgroup per CU (`slices` > 1): see launch_rollout_km.  RMAV_SLICE=0|1 overrides.
+bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
     static const int forced = [] {
         const char *e = getenv("RMAV_SPLIT");
         return e ? atoi(e) : -1;
     }();
+    static const int slice_forced = [] {
+        const char *e = getenv("RMAV_SLICE");
+        return e ? atoi(e) : -1;
+    }();
+    *slices = 1;
     if (a.n_steps < 8 || h->kind > RMAV_QUAD3D_SL) return false;
-    if (forced == 0 || forced == 1) return forced == 1;
-    return h->n <= kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
+    const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
+    if (forced == 0) return false;
+    if (h->n <= cap) return true;
+    if (slice_forced == 1 || (slice_forced != 0 && kSliceByDefault)) {
+        *slices = (int)((h->n + cap - 1) / cap);
+        return true;
+    }
+    return forced == 1;   // one launch beyond the capacity: only when asked for
 }
 
 template <int K, int MODE>
@@ -285,12 +300,26 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     } else {
         if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER) && K != REINMAV) {
             constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : ACT_CONTROLLER_SPLIT;
-            if (use_split(h, a, MODE == ACT_RANDOM)) {
-                switch (pick_store_policy(h, a, true)) {
-                case ST_STREAM: return launch_rollout_kms<K, SMODE, ST_STREAM>(h, a);
-                case ST_DEFAULT: return launch_rollout_kms<K, SMODE, ST_DEFAULT>(h, a);
-                default: return launch_rollout_kms<K, SMODE, ST_WRITE_THROUGH>(h, a);
+            int slices = 1;
+            if (use_split(h, a, MODE == ACT_RANDOM, &slices)) {
+                const int st = pick_store_policy(h, a, true);
+                // balanced slices, each a multiple of 64 envs
+                const int64_t per = slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;
+                for (int64_t first = 0; first < h->n; first += per) {
+                    RolloutArgs b = a;
+                    if (slices > 1) {
+                        b.slice_first = (uint32_t)first;
+                        b.slice_count = (uint32_t)((h->n - first < per) ? h->n - first : per);
+                    }
+                    int rc;
+                    switch (st) {
+                    case ST_STREAM: rc = launch_rollout_kms<K, SMODE, ST_STREAM>(h, b); break;
+                    case ST_DEFAULT: rc = launch_rollout_kms<K, SMODE, ST_DEFAULT>(h, b); break;
+                    default: rc = launch_rollout_kms<K, SMODE, ST_WRITE_THROUGH>(h, b); break;
+                    }
+                    if (rc) return rc;
                 }
+                return RMAV_OK;
             }
         }
         switch (pick_store_policy(h, a, false)) {

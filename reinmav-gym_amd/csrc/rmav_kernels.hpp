@@ -60,12 +60,16 @@ constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 // The sweet spot is ONE workgroup per CU: the host launches ceil(N / 16 384) pairs per workgroup (256 workgroups).
 constexpr int kSplitGroupMax = 8;   // 1024 threads
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
-    static constexpr int A_HALF = DRAWS ? kSplitChunk * NA * 64 : 0, A_WORDS = 2 * A_HALF;
+    // env-steps per hand-over: 2, but 1 for the 16-component slung-load state - its tiles then take 11.8 instead of
+    // 23.5 KB, so that 8 pairs (one workgroup per CU up to 131 072 envs) fit the 160 KiB of LDS; hand-over every 1 / 2 / 4
+    // env-steps measured the same in round 1
+    static constexpr int CH = (NS > 10) ? 1 : kSplitChunk;
+    static constexpr int A_HALF = DRAWS ? CH * NA * 64 : 0, A_WORDS = 2 * A_HALF;
     // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
     // trajectory is batch-major - both conflict-free to write), then reward[64], done[64]
     static constexpr int OBS_STRIDE = NS | 1, REW = OBS_STRIDE * 64, DONE = REW + 64;
     static constexpr int ACT = DONE + 64;   // actions [c][lane], only when the integrator computes them
-    static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = kSplitChunk * O_ROW, O_WORDS = 2 * O_HALF;
+    static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = CH * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
@@ -109,6 +113,9 @@ struct RolloutArgs {
     float *logp_out;        // [n_steps][N]
     float *val_out;         // [n_steps + 1][N]
     float *ctrl_out;        // ACT_BUFFER_CTRL only: control() of the state after the last step, [nA][N] | [N][nA]
+    // this launch covers envs [slice_first, slice_first + slice_count) of the handle's N (slice_count = 0: all of them);
+    // trajectory pitches stay N.  slice_first is a multiple of 64.
+    uint32_t slice_first, slice_count;
 };
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
@@ -179,11 +186,13 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     constexpr int AUX = StoreAux<ST>::value;
     // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
     constexpr bool SPLIT = is_split(MODE), DRAWS = (MODE == ACT_RANDOM_SPLIT);
+    [[maybe_unused]] constexpr int CH = SplitTile<NS, NA, DRAWS>::CH;   // env-steps per hand-over (split modes)
     // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
     const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
     const bool split_helper = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
     const uint32_t split_local = threadIdx.x - (split_helper ? 64u * split_g : 0u);
-    const uint32_t gi = SPLIT ? blockIdx.x * (64u * split_g) + split_local : blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gi = a.slice_first + (SPLIT ? blockIdx.x * (64u * split_g) + split_local : blockIdx.x * blockDim.x + threadIdx.x);
+    const uint32_t slice_end = a.slice_count ? a.slice_first + a.slice_count : (uint32_t)a.n;
     // SPLIT: this pair's hand-over tiles
     [[maybe_unused]] float *lds_p = lds_w;
     if constexpr (SPLIT)
@@ -195,8 +204,8 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     // so in that mode lanes past the end of the batch become clones of env N-1: they compute and store
     // exactly what that env's lane does; only the episode totals must not count them.
     const uint32_t ge = HALF ? ((gi >> 6) << 5) + (gi & 31u) : gi;                      // env this lane works on
-    const bool valid = ge < (uint64_t)n;
-    const uint32_t li = ((is_mfma_policy(MODE) || SPLIT) && !valid) ? (uint32_t)n - 1u : ge;   // local env index
+    const bool valid = ge < slice_end;
+    const uint32_t li = ((is_mfma_policy(MODE) || SPLIT) && !valid) ? slice_end - 1u : ge;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = (a.flags & F_AOS) != 0;
@@ -216,11 +225,11 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     // with the same pattern drains the trajectory at 7 TB/s (tools/micro/write_ceiling.hip: 36 us per 64 steps).
     // So each 64 envs get a second, "memory" wavefront:
     //   helper  (wave 1): draws the actions (Philox - a third of the instruction stream, independent of the
-    //                     state) kSplitChunk env-steps ahead into an LDS tile, and issues EVERY trajectory
+    //                     state) CH env-steps ahead into an LDS tile, and issues EVERY trajectory
     //                     store: actions directly, obs / reward / done from a second LDS tile the integrator
     //                     fills.  It is the only wavefront that ever waits on the memory pipeline.
     //   integrator (wave 0): state in registers, reads actions from LDS, writes its outputs to LDS.
-    // Both tiles are double-buffered; one s_barrier per kSplitChunk env-steps swaps the halves of both.
+    // Both tiles are double-buffered; one s_barrier per CH env-steps swaps the halves of both.
     //   helper:     fill A(0) | B0 | fill A(1)          | B1 | fill A(2), drain O(0) | B2 | ... | B(nc) | drain O(nc-1)
     //   integrator:            B0 | chunk 0: A(0)->O(0) | B1 | chunk 1: A(1)->O(1)   | B2 | ... | B(nc)
     // Same Philox counters, same arithmetic: same bits as ACT_RANDOM.  Lanes past the end of the batch are clones
@@ -233,11 +242,10 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             const uint64_t env_id = a.env_base + (uint64_t)li;
             const uint32_t lane = threadIdx.x & 63u;
             const int32_t T = a.n_steps;
-            const int32_t nc = (T + kSplitChunk - 1) / kSplitChunk;
+            const int32_t nc = (T + CH - 1) / CH;
             // batch-major obs: output dword 64 q + lane of this wavefront is component e % NS of its env e / NS
             const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
-            const uint32_t n_here = (uint64_t)wave_first + 64u <= (uint64_t)n ? 64u
-                                    : ((uint64_t)wave_first < (uint64_t)n ? (uint32_t)(n - wave_first) : 0u);
+            const uint32_t n_here = wave_first + 64u <= slice_end ? 64u : (wave_first < slice_end ? slice_end - wave_first : 0u);
             const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
             uint32_t aos_rd[NS];
 #pragma unroll
@@ -248,8 +256,8 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             auto fill = [&](int32_t c) {   // actions of chunk c: draw, hand over, write the action trajectory
                 float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
 #pragma unroll
-                for (int j = 0; j < kSplitChunk; ++j) {
-                    const int32_t k = c * kSplitChunk + j;
+                for (int j = 0; j < CH; ++j) {
+                    const int32_t k = c * CH + j;
                     if (k < T) {
                         float act[NA];
                         random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
@@ -273,8 +281,8 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             auto drain = [&](int32_t c) {  // obs / reward / done of chunk c: LDS -> trajectory
                 const float *buf = lds_p + ST_::A_WORDS + (c & 1) * ST_::O_HALF + lane;
 #pragma unroll
-                for (int j = 0; j < kSplitChunk; ++j) {
-                    const int32_t k = c * kSplitChunk + j;
+                for (int j = 0; j < CH; ++j) {
+                    const int32_t k = c * CH + j;
                     if (k < T) {
                         const float *row = buf + j * ST_::O_ROW;
                         if constexpr (!DRAWS) {
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
         }
     }
 
-    if (li < (uint64_t)n) {
+    if (li < slice_end) {
         const rsrc_t r_state = make_rsrc(a.state);
         float s[NS];
 #pragma unroll
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             // readfirstlane: tell the compiler these are wave-uniform (SGPR offsets, no waterfall loops)
             const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
             tile = lds_w + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * AosTile<NS>::WORDS;
-            full_wave = (uint64_t)wave_first + 64u <= (uint64_t)n;
+            full_wave = wave_first + 64u <= slice_end;
             wave_obs_base = wave_first * (uint32_t)(NS * 4);
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
@@ -513,13 +521,13 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
-                if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
-                const float *buf = lds_p + ((k / kSplitChunk) & 1) * SplitTile<NS, NA, true>::A_HALF +
-                                   (k % kSplitChunk) * (NA * 64) + (threadIdx.x & 63u);
+                if ((k % CH) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
+                const float *buf = lds_p + ((k / CH) & 1) * SplitTile<NS, NA, true>::A_HALF +
+                                   (k % CH) * (NA * 64) + (threadIdx.x & 63u);
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
             } else if constexpr (MODE == ACT_CONTROLLER_SPLIT) {
-                if ((k % kSplitChunk) == 0) __syncthreads();   // B(k / chunk): the output tile swaps halves
+                if ((k % CH) == 0) __syncthreads();   // B(k / chunk): the output tile swaps halves
                 env_control<K>(s, pc, act);
             } else if constexpr (K == REINMAV) {
 #pragma unroll
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
                 // hand obs / reward / done (and the controller's action) to the memory wavefront; it drains this
                 // half two barriers later
                 using ST_ = SplitTile<NS, NA, DRAWS>;
-                float *row = lds_p + ST_::A_WORDS + ((k / kSplitChunk) & 1) * ST_::O_HALF + (k % kSplitChunk) * ST_::O_ROW +
+                float *row = lds_p + ST_::A_WORDS + ((k / CH) & 1) * ST_::O_HALF + (k % CH) * ST_::O_ROW +
                              (threadIdx.x & 63u);
                 if (obs_out) {
                     if (aos) {   // env-major for the batch-major drain

@@ -12,9 +12,10 @@
 // * Layer 1 and layer 2 are fused in one loop over the 64 hidden units of layer 1: unit i is produced
 //   (nS FMAs + tanh) and immediately scattered into the 64 layer-2 accumulators, which stay in registers
 //   with static indices; the loop index is dynamic, so code size stays ~150 instructions per net.
-// * fp32 FMAs on the vector ALU (hipcc packs them into v_pk_fma_f32).  The fp32-input MFMA runs at the
-//   same FLOP rate as packed VALU, so it would buy < 2x for a non-trivial register-layout dance; the
-//   16x faster bf16 MFMA would break bitwise agreement with the fp32 learner.  See DESIGN.md section 8.
+// * fp32 FMAs on the vector ALU (hipcc packs them into v_pk_fma_f32).  The same nets on the fp32-input MFMA
+//   (same FLOP rate, ~40x fewer instructions) are rmav_policy_mfma32.hpp: 1.9x faster, same precision class, and
+//   the default fp32 actor since round 2; the 16x faster bf16 MFMA (rmav_policy_mfma.hpp) gives up bitwise-class
+//   agreement with the fp32 learner.  See DESIGN.md section 8.
 //
 // Weight buffer layout (fp32, H = 64, NSP = nS rounded up to a multiple of 4), per net, pi then vf:
 //   W1 [H][NSP] (row j = hidden unit j, zero padded) | b1 [H] | W2T [H][H] (W2T[i][j] = W2[j][i]) | b2 [H] |

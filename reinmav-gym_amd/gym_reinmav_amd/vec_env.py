@@ -54,9 +54,14 @@ class QuadrotorVecEnv:
         if self.numpy_io:
             actions = np.asarray(actions, dtype=np.float32)
         # enqueue on the env's stream; device outputs are filled asynchronously
-        self._pending = self.env.step(actions, layout="aos", out=self._sets[self._flip])
-        if self.reuse_buffers:
-            self._flip ^= 1
+        if self.reuse_buffers or self.numpy_io:
+            out = self._sets[self._flip]
+            if self.reuse_buffers:
+                self._flip ^= 1
+        else:   # fresh tensors every step (DummyVecEnv semantics): the kernel writes straight into them, no copies
+            out = (self.env._new((self.num_envs, self.env.nS), np.float32, True),
+                   self.env._new((self.num_envs,), np.float32, True), self.env._new((self.num_envs,), np.uint8, True))
+        self._pending = self.env.step(actions, layout="aos", out=out)
 
     def step_wait(self):
         assert self._pending is not None, "step_async() must precede step_wait()"
@@ -68,8 +73,7 @@ class QuadrotorVecEnv:
         elif self.reuse_buffers:
             done_b = done.view(torch.bool)      # the kernel writes 0 / 1: a bool view, no conversion launch
         else:
-            done_b = done.clone().view(torch.bool)
-            obs, rew = obs.clone(), rew.clone()
+            done_b = done.view(torch.bool)
         return obs, rew, done_b, self._infos(done_b)
 
     def step(self, actions):
