@@ -179,6 +179,40 @@ __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t sof
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, AUX);
 }
 
+// Wide drain of the hand-over tiles, built and measured, NOT the default: the memory wavefront
+// reads 4 consecutive envs of a column with one ds_read_b128 and stores them with one buffer_store_dwordx4 - lane
+// (cg = lane >> 4, eq = lane & 15) handles envs 4 eq .. 4 eq + 3 of column 4 j + cg - so a 64-env step of quadrotor3d
+// leaves in 10 memory instructions instead of 28.  Measured (profiles/r02/wide_drain_ab.md, cold buffers, three
+// interleaved repetitions): random-action rollouts 0-8 % slower, controller-driven ones 0-4 % faster; and the memory
+// system absorbs 16-byte and 4-byte stores at the same rate (tools/micro/store_patterns.hip).  -DRMAV_WIDE_DRAIN=1
+// builds it; both drains pass the parity suite bit for bit.
+#ifndef RMAV_WIDE_DRAIN
+#define RMAV_WIDE_DRAIN 0
+#endif
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <int AUX>
+__device__ __forceinline__ void buf_st4_aux(rsrc_t r, uint32_t voff, uint32_t soff, float4 v) {
+    u32x4_t d;
+    d[0] = __builtin_bit_cast(uint32_t, v.x);
+    d[1] = __builtin_bit_cast(uint32_t, v.y);
+    d[2] = __builtin_bit_cast(uint32_t, v.z);
+    d[3] = __builtin_bit_cast(uint32_t, v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, AUX);
+}
+// C feature-major columns of a tile (column c at words [64 c, 64 c + 64)) -> C SoA columns of `r` (pitch `col` bytes),
+// full 64-env wavefront starting at byte offset `wave_off` of each column
+template <int AUX, int C>
+__device__ __forceinline__ void wide_cols(const float *tile, rsrc_t r, uint32_t wave_off, uint32_t col, uint32_t lane) {
+    const uint32_t cg = lane >> 4, eq = lane & 15u;
+#pragma unroll
+    for (int j = 0; 4 * j < C; ++j) {
+        if (4 * j + 3 < C || 4 * j + (int)cg < C) {
+            const float4 v = *reinterpret_cast<const float4 *>(tile + (4 * j + cg) * 64u + 4u * eq);
+            buf_st4_aux<AUX>(r, wave_off + 16u * eq + cg * col, (uint32_t)(4 * j) * col, v);
+        }
+    }
+}
+
 template <int K, int MODE, int ST = ST_DEFAULT>
 __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
@@ -247,6 +281,10 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
             const uint32_t n_here = wave_first + 64u <= slice_end ? 64u : (wave_first < slice_end ? slice_end - wave_first : 0u);
             const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
+            // wave-uniform: the ragged last wavefront drains dword-wise, and so does a batch whose column pitch or done
+            // pointer would misalign the 16-byte / packed-byte stores
+            [[maybe_unused]] const bool wide = !aos && n_here == 64u && (n & 3) == 0 &&
+                                               (reinterpret_cast<uintptr_t>(a.done_out) & 3u) == 0;
             uint32_t aos_rd[NS];
 #pragma unroll
             for (int q = 0; q < NS; ++q) {
@@ -269,6 +307,10 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
                                 float *dst = dst_step + (int64_t)li * NA;
 #pragma unroll
                                 for (int q = 0; q < NA; ++q) dst[q] = act[q];
+                            } else if (RMAV_WIDE_DRAIN && wide) {
+                                // the tile the integrator will read is also the transposition buffer (LDS executes one
+                                // wavefront's accesses in order)
+                                wide_cols<AUX, NA>(buf - lane + j * NA * 64, make_rsrc(dst_step), wave_first * 4u, col, lane);
                             } else {
                                 const rsrc_t ra = make_rsrc(dst_step);
 #pragma unroll
@@ -280,6 +322,39 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
             };
             auto drain = [&](int32_t c) {  // obs / reward / done of chunk c: LDS -> trajectory
                 const float *buf = lds_p + ST_::A_WORDS + (c & 1) * ST_::O_HALF + lane;
+                if (RMAV_WIDE_DRAIN && wide) {
+                    const float *tile = buf - lane;
+#pragma unroll
+                    for (int j = 0; j < CH; ++j) {
+                        const int32_t k = c * CH + j;
+                        if (k < T) {
+                            const float *row = tile + j * ST_::O_ROW;
+                            if constexpr (!DRAWS) {
+                                if (a.act_out)
+                                    wide_cols<AUX, NA>(row + ST_::ACT, make_rsrc(a.act_out + (int64_t)k * NA * n), wave_first * 4u, col, lane);
+                            }
+                            if (a.obs_out) wide_cols<AUX, NS>(row, make_rsrc(a.obs_out + (int64_t)k * NS * n), wave_first * 4u, col, lane);
+                        }
+                    }
+                    // reward and done of the chunk's CH steps in one instruction each: lanes [16 j, 16 j + 16) take step j
+                    const uint32_t sj = lane >> 4, eq = lane & 15u;
+                    const int32_t k0 = c * CH;
+                    if (sj < (uint32_t)CH && k0 + (int32_t)sj < T) {
+                        const float *row = tile + sj * ST_::O_ROW;
+                        if (a.rew_out) {
+                            const float4 v = *reinterpret_cast<const float4 *>(row + ST_::REW + 4u * eq);
+                            buf_st4_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k0 * n), (wave_first + 4u * eq) * 4u + sj * col, 0u, v);
+                        }
+                        if (a.done_out) {
+                            const float4 d = *reinterpret_cast<const float4 *>(row + ST_::DONE + 4u * eq);
+                            const uint32_t bytes = (d.x != 0.0f ? 1u : 0u) | (d.y != 0.0f ? 0x100u : 0u) | (d.z != 0.0f ? 0x10000u : 0u) |
+                                                   (d.w != 0.0f ? 0x1000000u : 0u);
+                            __builtin_amdgcn_raw_buffer_store_b32(bytes, make_rsrc(a.done_out + (int64_t)k0 * n),
+                                                                  wave_first + 4u * eq + sj * (uint32_t)n, 0u, 0);
+                        }
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     const int32_t k = c * CH + j;

@@ -155,13 +155,19 @@ class NativeStatsExchange:
         dev = torch.device("cuda", env.device)
         on_gpu = dist.get_backend(group) == "nccl"
         uid = torch.zeros(A.COMM_ID_BYTES, dtype=torch.uint8)
+        err = None
         if self.rank == 0:
-            buf = (C.c_char * A.COMM_ID_BYTES)()
-            A.check(L.rmav_comm_unique_id(buf))
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            try:   # a failure here must still reach the broadcast below, or the other ranks would wait for ever
+                buf = (C.c_char * A.COMM_ID_BYTES)()
+                A.check(L.rmav_comm_unique_id(buf))
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            except Exception as e:  # pragma: no cover
+                err = e
         uid = uid.to(dev) if on_gpu else uid
         dist.broadcast(uid, src=0, group=group)
         raw = bytes(uid.cpu().numpy().tobytes())
+        if err is not None or not any(raw):   # all-zero id = rank 0 could not create one: every rank raises
+            raise RuntimeError(f"no RCCL unique id from rank 0 ({err!r})")
         self._comm = C.c_void_p()
         A.check(L.rmav_comm_create(C.byref(self._comm), raw, self.rank, self.world, env.device))
         self.ret = torch.empty(self.n_total, dtype=torch.float32, device=dev)
