@@ -19,7 +19,9 @@ One bench "step" = ONE launch of the hot-path kernel over the rank's whole shard
       (what a policy would have written), state updated in place (obs == state), reward/done written.
 
 value = (envs on all ranks) * chunk * K / max-over-ranks wall time of the K timed launches (inputs already
-resident in HBM; barrier + synchronize on both sides).  For N > 1 every rollout launch is followed by the one
+resident in HBM; barrier + synchronize on both sides; the W warm-up launches are preceded by ``--prewarm-ms`` (40 ms) of
+the same untimed launches, because the first ~5 ms of GPU work after idle run ~15 % slow on these boxes and a short
+--steps / --warmup would otherwise measure the clock ramp).  For N > 1 every rollout launch is followed by the one
 collective the path has: the RCCL all-gather of per-env episode returns/lengths (packed by one small launch,
 gathered on a second stream so that it overlaps the next rollout).
 
@@ -119,6 +121,8 @@ def main():
     ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
     ap.add_argument("--in-place", action="store_true", help="rollout mode: rewrite ONE trajectory buffer set (cache-assisted)")
     ap.add_argument("--ring", type=int, default=0, help="rollout mode: number of trajectory buffer sets (0 = >= 5 and > 1.5 GB)")
+    ap.add_argument("--prewarm-ms", type=float, default=40.0,
+                    help="untimed stretch of the headline's launches before the --warmup launches (GPU clock ramp; 0 = none)")
     ap.add_argument("--exchange-every", type=int, default=1,
                     help="multi-rank runs: post the episode-stats all-gather after every k-th rollout launch (default 1 = every launch)")
     ap.add_argument("--action-ring", type=int, default=64, help="step mode: number of pre-generated action buffers")
@@ -255,8 +259,16 @@ def main():
                     k -= m
             return run, 1, 1
 
-        def measure(mode, chunk, K, W, in_place=False):
+        def measure(mode, chunk, K, W, in_place=False, prewarm_ms=0.0):
             run, per_launch, R = make_runner(mode, chunk, in_place)
+            if prewarm_ms > 0:
+                # The first ~5 ms of GPU work after idle run ~15 % slow on these boxes (clock ramp).  A short --steps /
+                # --warmup (the driver runs 20 / 5) would sit entirely inside that ramp, so the headline is preceded by an
+                # untimed stretch of the same launches; then come the W warm-up launches and the K timed ones.
+                t_pre = time.perf_counter()
+                while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
+                    run(16)
+                    stream.synchronize()
             run(W)
             stream.synchronize()
             if use_dist:
@@ -301,7 +313,8 @@ def main():
                     "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
         # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
-        wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place)
+        wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
+                                                           prewarm_ms=args.prewarm_ms)
         totals = env.episode_totals()
         if use_dist:
             totals = all_reduce_totals(totals, device="cpu" if gloo else dev)

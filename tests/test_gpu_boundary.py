@@ -169,3 +169,40 @@ def test_pack_stats_is_the_allgather_payload(G):
     assert np.array_equal(s[:n].view(np.float32), eb["last_return"]) and np.array_equal(s[cmax:cmax + n], eb["last_length"])
     assert (s[n:cmax] == 0).all() and (s[cmax + n:] == 0).all()
     env.close()
+
+
+def test_error_behaviour_of_the_new_entry_points(G):
+    """Same conventions as the rest of the ABI: status codes + rmav_last_error, nothing throws or aborts."""
+    import torch
+
+    A = G._abi
+    L = A.lib()
+    env = G.BatchedQuadrotor("quad3d", 256, track_episodes=False)
+    z = C.c_void_p(0)
+    rew = torch.zeros((4, 256), device="cuda")
+    done = torch.zeros((4, 256), dtype=torch.uint8, device="cuda")
+    val = torch.zeros((5, 256), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    assert L.rmav_gae(env._h, 0, p(rew), p(done), p(val), 0.99, 0.95, 1.0, p(rew), p(rew), z) == A.ERR_INVALID
+    assert L.rmav_gae(env._h, 4, z, p(done), p(val), 0.99, 0.95, 1.0, p(rew), p(rew), z) == A.ERR_INVALID
+    assert b"required" in L.rmav_last_error()
+    assert L.rmav_gae(None, 4, p(rew), p(done), p(val), 0.99, 0.95, 1.0, p(rew), p(rew), z) == A.ERR_INVALID
+    assert L.rmav_normalize(env._h, C.c_void_p(rew.data_ptr() + 4), 8, 0.0, 1.0) == A.ERR_INVALID     # not 16-byte aligned
+    assert L.rmav_normalize(env._h, p(rew), 0, 0.0, 1.0) == A.OK
+    a = np.zeros((256, 4), np.float32)
+    o = np.zeros((256, 10), np.float32)
+    assert L.rmav_step_control(env._h, a.ctypes.data, o.ctypes.data, None, None, None, A.HOST, A.AOS) == A.ERR_INVALID
+    assert L.rmav_step_control(env._h, None, o.ctypes.data, None, None, a.ctypes.data, A.HOST, A.AOS) == A.ERR_INVALID
+    assert L.rmav_pack_stats(env._h, 256, p(val)) == A.ERR_INVALID          # created without episode tracking
+    tr = G.BatchedQuadrotor("quad3d", 256)
+    assert L.rmav_pack_stats(tr._h, 128, p(val)) == A.ERR_INVALID           # cmax < num_envs
+    assert L.rmav_comm_create(None, None, 0, 1, 0) == A.ERR_INVALID
+    c = C.c_void_p()
+    assert L.rmav_comm_create(C.byref(c), None, 0, 1, 0) == A.ERR_INVALID and not c.value
+    assert L.rmav_allgather_stats_post(tr._h, None, 256) == A.ERR_INVALID
+    rm = G.BatchedQuadrotor("reinmav", 8)
+    s13 = np.zeros((8, 13), np.float32)
+    assert L.rmav_step_control(rm._h, a[:8].ctypes.data, s13.ctypes.data, None, None, a[:8].ctypes.data, A.HOST, A.AOS) == A.ERR_INVALID
+    assert b"ReinmavEnv" in L.rmav_last_error()
+    for e in (env, tr, rm):
+        e.close()
