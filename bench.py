@@ -265,10 +265,11 @@ def main():
                 # The first ~5 ms of GPU work after idle run ~15 % slow on these boxes (clock ramp).  A short --steps /
                 # --warmup (the driver runs 20 / 5) would sit entirely inside that ramp, so the headline is preceded by an
                 # untimed stretch of the same launches; then come the W warm-up launches and the K timed ones.
-                t_pre = time.perf_counter()
-                while (time.perf_counter() - t_pre) * 1e3 < prewarm_ms:
-                    run(16)
-                    stream.synchronize()
+                # (a launch COUNT derived from the problem size, not a wall-clock loop: every rank must issue the same
+                # number of launches - each one posts a collective)
+                est_us = (0.72 * per_launch if mode == "rollout" else 5.0) * max(1.0, n / 65536.0)
+                run(max(1, int(prewarm_ms * 1e3 / est_us)))
+                stream.synchronize()
             run(W)
             stream.synchronize()
             if use_dist:
