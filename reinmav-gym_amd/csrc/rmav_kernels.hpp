@@ -246,8 +246,12 @@ __global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) voi
     const bool track = (a.flags & F_TRACK) != 0;
     const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
 
-    // (the hosts rejects n_steps <= 0; the two-wavefront barrier protocol below needs at least one step)
-    if (a.n_steps <= 0) return;
+    // (the host rejects n_steps <= 0; the two-wavefront barrier protocol below needs at least one step.  Only there:
+    // the same guard in front of the one-wavefront variants made hipcc restructure their step loop and cost them
+    // 33-38 VGPRs, i.e. two to three wavefronts per SIMD of occupancy)
+    if constexpr (is_split(MODE)) {
+        if (a.n_steps <= 0) return;
+    }
 
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;
