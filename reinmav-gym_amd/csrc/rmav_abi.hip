@@ -223,7 +223,8 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
 // N <= 16 384 x (pairs that fit one workgroup for this kind and action source).
 template <int K, bool DRAWS> constexpr int split_pairs_max() {
     constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * SplitTile<Dims<K>::NS, Dims<K>::NA, DRAWS>::WORDS));
-    return by_lds < kSplitGroupMax ? by_lds : kSplitGroupMax;
+    constexpr int cap = split_group_cap<K, DRAWS>();   // threads / registers (rmav_kernels.hpp)
+    return by_lds < cap ? by_lds : cap;
 }
 constexpr int kSplitPairsRandom[4] = {split_pairs_max<QUAD2D, true>(), split_pairs_max<QUAD2D_SL, true>(),
                                       split_pairs_max<QUAD3D, true>(), split_pairs_max<QUAD3D_SL, true>()};
@@ -251,7 +252,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
         }();
         constexpr int g_max = split_pairs_max<K, MODE == ACT_RANDOM_SPLIT>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
-        int g = (forced >= 1 && forced <= kSplitGroupMax) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
+        int g = (forced >= 1 && forced <= g_max) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
         if (g < 1) g = 1;
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;

@@ -59,6 +59,18 @@ constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 // but 45 -> 64 us at 65 536 envs, where 8 pairs leave half of the CUs empty and put two integrators on every SIMD.
 // The sweet spot is ONE workgroup per CU: the host launches ceil(N / 16 384) pairs per workgroup (256 workgroups).
 constexpr int kSplitGroupMax = 8;   // 1024 threads
+// ... which caps the kernel at 128 VGPRs.  The integrator of a controller-driven slung-load rollout (fp64 controller
+// on top of the fp64 step) needs more and would spill to scratch: those variants stay at 4 pairs (512 threads).
+template <int K, bool DRAWS> constexpr int split_group_cap() {
+    return (!DRAWS && (K == QUAD2D_SL || K == QUAD3D_SL)) ? 4 : kSplitGroupMax;
+}
+#ifndef RMAV_KBLOCK
+#define RMAV_KBLOCK 256
+#endif
+constexpr int kBlock = RMAV_KBLOCK;  // upper bound (launch bounds); the launch may use 64/128/256 (.. RMAV_KBLOCK)
+template <int K, int MODE> constexpr int rollout_threads_max() {   // launch bounds of k_rollout<K, MODE, *>
+    return is_split(MODE) ? 128 * split_group_cap<K, MODE == ACT_RANDOM_SPLIT>() : kBlock;
+}
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     // env-steps per hand-over: 2, but 1 for the 16-component slung-load state - its tiles then take 11.8 instead of
     // 23.5 KB, so that 8 pairs (one workgroup per CU up to 131 072 envs) fit the 160 KiB of LDS; hand-over every 1 / 2 / 4
@@ -74,10 +86,6 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
 };
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
 
-#ifndef RMAV_KBLOCK
-#define RMAV_KBLOCK 256
-#endif
-constexpr int kBlock = RMAV_KBLOCK;  // upper bound (launch bounds); the launch may use 64/128/256 (.. RMAV_KBLOCK)
 
 struct Totals {
     unsigned long long episodes;
@@ -214,7 +222,7 @@ __device__ __forceinline__ void wide_cols(const float *tile, rsrc_t r, uint32_t 
 }
 
 template <int K, int MODE, int ST = ST_DEFAULT>
-__global__ __launch_bounds__(is_split(MODE) ? 128 * kSplitGroupMax : kBlock) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
+__global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;

@@ -167,11 +167,15 @@ __device__ __forceinline__ void policy_forward_mfma(const float (&x)[16], float 
     // Own tile (Nt == h): own components.  Other tile: the partner lane l ^ 32 owns that env; it needs my
     // components [8 (1-h), ...) for its own fragment, I need its components [8h, ...).
     bf16x8_t own, other;
+    const uint32_t hmask = 0u - h;   // h = 1: all ones
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         // (the state is pre-multiplied by k = 2 log2 e so that layer 1's accumulators hold k z, see act_frag)
-        const float mine = kTanhScale * (h ? x[8 + j] : x[j]);        // x[8h + j]
-        const float send = kTanhScale * (h ? x[j] : x[8 + j]);        // x[8(1-h) + j]: what the partner's fragment needs
+        // bit selection (v_bfi_b32) instead of `h ? x[8 + j] : x[j]`: LLVM may fold such a select into a dynamically
+        // indexed load, which puts the state array into scratch memory (it did for the 13-component ReinmavEnv state)
+        const uint32_t lo = __builtin_bit_cast(uint32_t, x[j]), hi = __builtin_bit_cast(uint32_t, x[8 + j]);
+        const float mine = kTanhScale * __builtin_bit_cast(float, (hi & hmask) | (lo & ~hmask));        // x[8h + j]
+        const float send = kTanhScale * __builtin_bit_cast(float, (lo & hmask) | (hi & ~hmask));        // x[8(1-h) + j]: what the partner's fragment needs
         const float recv = __shfl_xor(send, 32, 64);
         own[j] = (__bf16)mine;
         other[j] = (__bf16)recv;

@@ -54,9 +54,11 @@ struct Mfma32Layout {
 
 // NOUT = 4 (policy mean, zero padded) or 1 (value).  b_in[s]: layer-1 B operand of slice s (lane (n, h): component
 // 2 s + h of the env of column n), NSL = ceil(nS / 2) slices.  Returns the outputs for column n in BOTH half-waves.
+struct Mfma32In { float v[8]; };   // by value: a reference parameter of a real function would live on the stack
 template <int NSL, int NOUT>
-__device__ __noinline__ float4 mlp_mfma32(const float (&b_in)[8], uint32_t net) {
+__device__ __noinline__ float4 mlp_mfma32(Mfma32In bin, uint32_t net) {
     using L = Mfma32Layout;
+    const float (&b_in)[8] = bin.v;
     asm volatile("" : "+v"(net));   // keep LLVM from hoisting the weight reads out of the env-step loop
     const float *w = lds_w + net;
     const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
@@ -134,9 +136,19 @@ template <int NS>
 __device__ __forceinline__ void policy_forward_mfma32(const float (&x)[16], float (&mean)[4], float &value) {
     constexpr int NSL = (NS + 1) / 2;
     const uint32_t h = (threadIdx.x & 63u) >> 5;
-    float b[8];
+    // component 2 s + h by bit selection (v_bfi_b32): written as `h ? x[2 s + 1] : x[2 s]` LLVM folds the select into a
+    // dynamically indexed load and the state array lands in scratch memory (80 bytes per lane, one round trip per step)
+    const uint32_t hmask = 0u - h;   // h = 1: all ones
+    Mfma32In b;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) b[s] = (s < NSL) ? (h ? x[2 * s + 1] : x[2 * s]) : 0.0f;
+    for (int s = 0; s < 8; ++s) {
+        if (s < NSL) {
+            const uint32_t lo = __builtin_bit_cast(uint32_t, x[2 * s]), hi = __builtin_bit_cast(uint32_t, x[2 * s + 1]);
+            b.v[s] = __builtin_bit_cast(float, (hi & hmask) | (lo & ~hmask));
+        } else {
+            b.v[s] = 0.0f;
+        }
+    }
     const float4 m = mlp_mfma32<NSL, 4>(b, 0u);
     const float4 v = mlp_mfma32<NSL, 1>(b, (uint32_t)Mfma32Layout::NET);
     mean[0] = m.x; mean[1] = m.y; mean[2] = m.z; mean[3] = m.w;

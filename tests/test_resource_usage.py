@@ -1,0 +1,70 @@
+"""Register / scratch budget of the gfx950 kernels, from hipcc's -Rpass-analysis=kernel-resource-usage (`make asm`,
+no GPU needed).  A guard against silent codegen regressions: in round 2 an innocent `if (n_steps <= 0) return;` in
+front of the step loop cost the one-wavefront rollout kernels 33-38 VGPRs (two to three wavefronts per SIMD of
+occupancy) and a `h ? x[a] : x[b]` select put a state array into scratch memory, and nothing failed."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "reinmav-gym_amd")
+
+
+@pytest.fixture(scope="module")
+def usage():
+    subprocess.run(["make", "-s", "-C", PKG, "asm"], check=True)
+    txt = open(os.path.join(PKG, "build", "resource_usage.txt")).read()
+    out = {}
+    for b in re.split(r"remark: Function Name: ", txt)[1:]:
+        name = b.split(" ")[0]
+        out[name] = {k: int(re.search(pat, b).group(1)) for k, pat in (
+            ("vgpr", r"VGPRs: (\d+)"), ("agpr", r"AGPRs: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+            ("spill", r"VGPRs Spill: (\d+)"), ("occ", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)"))}
+    assert len(out) >= 100
+    return out
+
+
+def _k(usage, kind, mode, st):
+    hits = [v for n, v in usage.items() if n.startswith(f"_ZN4rmav9k_rolloutILi{kind}ELi{mode}ELi{st}E")]
+    assert len(hits) == 1, (kind, mode, st)
+    return hits[0]
+
+
+def test_no_kernel_uses_scratch(usage):
+    """Everything lives in registers / LDS.  Known exception: the bf16 actor of the 13-state ReinmavEnv (32 bytes)."""
+    bad = {n: v["scratch"] for n, v in usage.items() if v["scratch"] and not n.startswith("_ZN4rmav9k_rolloutILi4ELi4E")}
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("kind,budget,min_occ", [(0, 64, 7), (1, 104, 4), (2, 80, 6), (3, 144, 3)])
+def test_one_wavefront_rollout_register_budget(usage, kind, budget, min_occ):
+    """k_rollout<K, ACT_RANDOM | ACT_BUFFER | ACT_CONTROLLER, ST_STREAM | ST_DEFAULT>: the big-batch kernels live on
+    occupancy (4-16 wavefronts per SIMD hide the store latency)."""
+    for mode, st in ((1, 2), (1, 0), (0, 0)):
+        u = _k(usage, kind, mode, st)
+        assert u["vgpr"] <= budget and u["occ"] >= min_occ and u["spill"] == 0, (kind, mode, st, u)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+def test_two_wavefront_rollout_fits_1024_threads(usage, kind):
+    """The random-action two-wavefront kernels launch up to 8 pairs (1024 threads): <= 128 VGPRs, no spills."""
+    for st in (0, 1, 2):
+        u = _k(usage, kind, 5, st)
+        assert u["vgpr"] <= 128 and u["spill"] == 0, (kind, st, u)
+    u = _k(usage, kind, 6, 1)      # controller-driven: 4 pairs (512 threads, 256 VGPRs) for the slung-load kinds
+    assert u["spill"] == 0 and u["vgpr"] <= (256 if kind in (1, 3) else 128), (kind, u)
+
+
+def test_single_step_kernel_is_small(usage):
+    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav6k_stepILi2ELb0E")}
+    assert len(hits) == 1
+    u = next(iter(hits.values()))
+    assert u["vgpr"] <= 48 and u["occ"] == 8 and u["lds"] == 0, u
+
+
+def test_fp32_mfma_actor_leaves_room_for_two_wavefronts_per_simd(usage):
+    for kind in (0, 1, 2, 3):
+        u = _k(usage, kind, 8, 0)
+        assert u["vgpr"] + u["agpr"] <= 256 and u["spill"] == 0, (kind, u)
