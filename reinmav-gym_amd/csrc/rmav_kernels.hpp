@@ -291,7 +291,13 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             const int32_t nc = (T + CH - 1) / CH;
             // batch-major obs: output dword 64 q + lane of this wavefront is component e % NS of its env e / NS
             const uint32_t wave_first = __builtin_amdgcn_readfirstlane(gi - lane);
-            const uint32_t n_here = wave_first + 64u <= slice_end ? 64u : (wave_first < slice_end ? slice_end - wave_first : 0u);
+            // (the end of the slice again, as a 64-bit value of its own: derived from the kernel-scope `slice_end` - 32-bit, or
+            // widened - hipcc stopped treating the trajectory descriptors below as wave-uniform and wrapped every store of
+            // this wavefront in a waterfall loop: 243 v_readfirstlane in the quadrotor3d kernel instead of 3.
+            // tests/test_resource_usage.py counts them.)
+            const int64_t end64 = a.slice_count ? (int64_t)a.slice_first + (int64_t)a.slice_count : n;
+            const uint32_t n_here = (uint64_t)wave_first + 64u <= (uint64_t)end64 ? 64u
+                                    : ((uint64_t)wave_first < (uint64_t)end64 ? (uint32_t)(end64 - wave_first) : 0u);
             const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
             // wave-uniform: the ragged last wavefront drains dword-wise, and so does a batch whose column pitch or done
             // pointer would misalign the 16-byte / packed-byte stores

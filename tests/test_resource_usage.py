@@ -68,3 +68,28 @@ def test_fp32_mfma_actor_leaves_room_for_two_wavefronts_per_simd(usage):
     for kind in (0, 1, 2, 3):
         u = _k(usage, kind, 8, 0)
         assert u["vgpr"] + u["agpr"] <= 256 and u["spill"] == 0, (kind, u)
+
+
+def _kernel_asm(prefix):
+    path = os.path.join(PKG, "build", "rmav_abi.gfx950.s")
+    out, on = [], False
+    for line in open(path):
+        if not on and line.startswith(prefix):
+            on = True
+        if on:
+            out.append(line)
+            if "s_endpgm" in line:
+                break
+    assert out, prefix
+    return out
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [5, 6])
+def test_two_wavefront_kernels_have_no_waterfall_loops(usage, kind, mode):
+    """hipcc wraps a buffer access in a v_readfirstlane / s_and_saveexec loop when it cannot prove the descriptor
+    wave-uniform (guide T20).  The memory wavefront issues ~30 stores per env-step: in round 2 a harmless-looking
+    rewrite of one bounds expression made every one of them a loop (243 v_readfirstlane in the quadrotor3d kernel)."""
+    asm = _kernel_asm(f"_ZN4rmav9k_rolloutILi{kind}ELi{mode}ELi1E")
+    n_rfl = sum("v_readfirstlane" in l for l in asm)
+    assert n_rfl <= 8, n_rfl
