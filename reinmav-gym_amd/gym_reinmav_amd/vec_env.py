@@ -70,10 +70,8 @@ class QuadrotorVecEnv:
         if self.numpy_io:
             done_b = done.astype(bool)
             obs, rew = obs.copy(), rew.copy()
-        elif self.reuse_buffers:
-            done_b = done.view(torch.bool)      # the kernel writes 0 / 1: a bool view, no conversion launch
         else:
-            done_b = done.view(torch.bool)
+            done_b = done.view(torch.bool)      # the kernel writes 0 / 1: a bool view, no conversion launch
         return obs, rew, done_b, self._infos(done_b)
 
     def step(self, actions):
