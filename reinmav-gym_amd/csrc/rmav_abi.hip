@@ -1347,6 +1347,15 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     if (dbg == 1) {   // diagnostic: no collective at all
     } else if (dbg == 2) {   // diagnostic: a plain copy instead of the RCCL kernel (single rank only)
         HIP_TRY(hipMemcpyAsync(c->recv[k], c->send[k], (size_t)(2 * cmax) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
+    } else if (dbg == 3) {
+        // diagnostic: a stand-in for the kernel of a multi-GPU ring all-gather that waits for its peers - RMAV_DBG_OCC_WGS
+        // workgroups of 256 threads with RMAV_DBG_OCC_LDS bytes of LDS hold CU slots for RMAV_DBG_OCC_US microseconds
+        static const int wgs = [] { const char *e = getenv("RMAV_DBG_OCC_WGS"); return e ? atoi(e) : 16; }();
+        static const int lds = [] { const char *e = getenv("RMAV_DBG_OCC_LDS"); return e ? atoi(e) : 32768; }();
+        static const int us = [] { const char *e = getenv("RMAV_DBG_OCC_US"); return e ? atoi(e) : 80; }();
+        hipLaunchKernelGGL(k_occupy, dim3(wgs), dim3(256), (size_t)lds, c->stream, (uint64_t)us * 100ull /* 100 MHz counter */,
+                           (uint32_t *)c->recv[k]);
+        HIP_TRY(hipGetLastError());
     } else
     RCCL_TRY(R->AllGather(c->send[k], c->recv[k], (size_t)(2 * cmax), ncclInt32, c->comm, c->stream));
     HIP_TRY(hipEventRecord(c->done[k], c->stream));

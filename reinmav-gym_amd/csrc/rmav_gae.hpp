@@ -139,10 +139,28 @@ __global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ la
     send[i] = i < count ? __float_as_int(last_ret[i]) : 0;
     send[cmax + i] = i < count ? last_len[i] : 0;
 }
-// one thread: publish `seq` in a signal word another HIP stream waits on with hipStreamWaitValue32 (the kernel
-// boundary in front of this launch has released the payload)
+// one thread: publish `seq` in a signal word another HIP stream waits on with hipStreamWaitValue32 (the kernel boundary
+// in front of this launch has released the payload).  Folding this into k_pack_stats - every workgroup releases and takes
+// a ticket, the last one signals - measured SLOWER (exchange cost per 131 072-env rollout +15..19 us instead of +9..15:
+// 512 agent-scope releases each write the L2 back) - profiles/r02/handover_chunk.md.
 __global__ void k_signal(uint32_t *flag, uint32_t seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// diagnostic stand-in for a collective's kernel (RMAV_DBG_EXCHANGE=3): workgroups that hold their CU slots - threads,
+// registers and `extern` LDS - for `cycles` ticks of the 100 MHz wall clock without touching memory, like a ring all-gather waiting for
+// its peers.  Used to measure how the rollout kernels tolerate a co-resident communication kernel on ONE GPU.
+__global__ void k_occupy(uint64_t cycles, uint32_t *sink) {
+    extern __shared__ uint32_t occ_lds[];
+    const uint64_t t0 = wall_clock64();   // constant 100 MHz counter
+    uint32_t spins = 0;
+    while (wall_clock64() - t0 < cycles) {
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+    }
+    if (cycles == ~0ull) {   // never: keeps the LDS allocation and the loop alive
+        occ_lds[threadIdx.x] = spins;
+        sink[0] = occ_lds[0];
+    }
 }
 // recv = [world][2][cmax] -> returns_out / lengths_out [n_total] in global env order (rank r owns
 // base + (r < rem) envs starting at r * base + min(r, rem))

@@ -45,8 +45,12 @@ constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == A
 constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
 // Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
 // (actions: helper -> integrator, only when the helper draws them; obs + reward + done [+ actions]: integrator -> helper)
+// 1: the tiles of 8 pairs take 70 KB (quad3d) instead of 136 KB of the CU's 160 KB, so a communication kernel's
+// workgroups (the overlapped statistics exchange) can share the CU with a rollout workgroup - with 2, a rollout next to a
+// 60-80 us co-resident kernel measured +22..29 us at 131 072 envs, with 1 +10..11 us - and alone it is as fast or faster
+// (profiles/r02/handover_chunk.md).
 #ifndef RMAV_SPLIT_CHUNK
-#define RMAV_SPLIT_CHUNK 2
+#define RMAV_SPLIT_CHUNK 1
 #endif
 constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 // Split modes: (integrator, memory wavefront) pairs per workgroup - a launch parameter (blockDim.x / 128, 1 .. 8).
@@ -72,10 +76,7 @@ template <int K, int MODE> constexpr int rollout_threads_max() {   // launch bou
     return is_split(MODE) ? 128 * split_group_cap<K, MODE == ACT_RANDOM_SPLIT>() : kBlock;
 }
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
-    // env-steps per hand-over: 2, but 1 for the 16-component slung-load state - its tiles then take 11.8 instead of
-    // 23.5 KB, so that 8 pairs (one workgroup per CU up to 131 072 envs) fit the 160 KiB of LDS; hand-over every 1 / 2 / 4
-    // env-steps measured the same in round 1
-    static constexpr int CH = (NS > 10) ? 1 : kSplitChunk;
+    static constexpr int CH = kSplitChunk;   // env-steps per hand-over
     static constexpr int A_HALF = DRAWS ? CH * NA * 64 : 0, A_WORDS = 2 * A_HALF;
     // one env-step of outputs: obs (feature-major [c][lane], or env-major [lane][c] with an odd row stride when the
     // trajectory is batch-major - both conflict-free to write), then reward[64], done[64]
