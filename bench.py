@@ -98,6 +98,58 @@ def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: 
     }
 
 
+class DeviceSampler:
+    """Socket power and shader clock of THIS rank's GPU while the headline workload runs (hwmon / sysfs of the device's
+    PCI function, read every 10 ms from a thread).  Context for ``roofline``: the fused rollout runs the package at its
+    power cap (1.3-1.4 kW of 1.4 kW; a fill kernel of the same bytes draws 0.93 kW), and how a box's power management
+    reacts is the +-10 % spread between boxes (profiles/r02/power.md).  Every field is None when sysfs is unreadable."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+
+        import torch
+
+        self.samples, self._stop, self.cap = [], False, None
+        self._pow = self._clk = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            d = f"/sys/bus/pci/devices/{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            hw = sorted(glob.glob(d + "/hwmon/hwmon*"))[0]
+            self._pow = next(f for f in (hw + "/power1_input", hw + "/power1_average") if os.path.exists(f))
+            self._clk = hw + "/freq1_input"
+            self.cap = int(open(hw + "/power1_cap").read()) / 1e6
+        except Exception:
+            pass
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop:
+            try:
+                self.samples.append((int(open(self._pow).read()) / 1e6, int(open(self._clk).read()) / 1e6))
+            except Exception:
+                pass
+            time.sleep(0.01)
+
+    def __enter__(self):
+        if self._pow:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._pow:
+            self._thread.join()
+
+    def summary(self):
+        busy = [x for x in self.samples if x[0] > 0.5 * max(p for p, _ in self.samples)] if self.samples else []
+        if not busy:
+            return {"power_w_mean": None, "power_w_max": None, "power_cap_w": self.cap, "sclk_mhz_mean": None, "samples": 0}
+        return {"power_w_mean": round(sum(p for p, _ in busy) / len(busy), 1), "power_w_max": round(max(p for p, _ in busy), 1),
+                "power_cap_w": self.cap, "sclk_mhz_mean": round(sum(c for _, c in busy) / len(busy)), "samples": len(busy),
+                "note": "hwmon power1 / freq1 of this GPU every 10 ms over the prewarm + warm-up + timed launches of the headline workload; the power sensor is a moving average, so a run shorter than ~1 s under-reads (steady state: 1.32-1.40 kW, profiles/r02/power.md)"}
+
+
 def fused_bytes_per_launch(n: int, chunk: int, nS: int, nA: int) -> int:
     """What one fused rollout launch must move (see the module docstring)."""
     return n * (chunk * (4 * (nS + nA + 1) + 1) + 8 * nS + 24)
@@ -314,8 +366,10 @@ def main():
                     "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
         # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
         # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
-        wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
-                                                           prewarm_ms=args.prewarm_ms)
+        with DeviceSampler(dev.index or 0) as sampler:
+            wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
+                                                               prewarm_ms=args.prewarm_ms)
+        device_state = sampler.summary()
         totals = env.episode_totals()
         if use_dist:
             totals = all_reduce_totals(totals, device="cpu" if gloo else dev)
@@ -415,6 +469,7 @@ def main():
                 "algorithmic_equiv_bytes_per_env_step": algo_bytes,
                 "algorithmic_equiv_frac": algo_bytes * n * per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             },
+            "device_state": device_state,
         }
         if other:
             line["other_modes"] = other
