@@ -371,6 +371,28 @@ def main():
                                                                prewarm_ms=args.prewarm_ms)
         device_state = sampler.summary()
         totals = env.episode_totals()
+        exchange_check = None
+        if use_dist and exchange is not None and args.mode == "rollout":
+            # outside the timed region: one more exchange of the final per-env statistics, checked element by element
+            # against a plain torch.distributed all-gather of the same buffers (global env order = rank order here)
+            eb = env.episode_buffers(device_out=not gloo)
+            mine = [torch.as_tensor(eb["last_return"]), torch.as_tensor(eb["last_length"])]
+            if gloo:
+                exchange.post(mine[0], mine[1])
+            else:
+                exchange.post(env=env)
+            got = [t.clone() for t in exchange.result()]
+            torch.cuda.synchronize()
+            ref = [torch.empty(n_total, dtype=t.dtype, device=t.device) for t in mine]
+            for r_, m_ in zip(ref, mine):
+                dist.all_gather_into_tensor(r_, m_.contiguous())
+            exchange_check = bool(torch.equal(got[0].to(ref[0].device).view(torch.int32), ref[0].view(torch.int32))
+                                  and torch.equal(got[1].to(ref[1].device), ref[1]))
+            okf = torch.tensor([int(exchange_check)], dtype=torch.int32, device="cpu" if gloo else dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)   # rank 0 reports for every rank
+            if not exchange_check:
+                print(f"[rank {rank}] the gathered episode statistics differ from torch.distributed's all-gather", file=sys.stderr)
+            exchange_check = bool(okf.item())
         if use_dist:
             totals = all_reduce_totals(totals, device="cpu" if gloo else dev)
         if gathered is not None:
@@ -450,6 +472,7 @@ def main():
                 if use_dist else "single GPU",
                 "finished_episodes": totals["episodes"],
                 "gathered_envs_with_a_finished_episode": gathered_finished,
+                "exchange_equals_plain_all_gather": exchange_check,
             },
             "roofline": {
                 "bound": "hbm",

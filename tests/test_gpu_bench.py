@@ -65,6 +65,7 @@ def test_bench_two_ranks_on_one_gpu(built):
     # keyed by global env id: the sharded run finishes exactly the episodes of the unsharded one
     assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
+    assert j2["config"]["exchange_equals_plain_all_gather"] is True
     assert 0.0 < j2["roofline"]["frac"] <= 1.0
 
 
@@ -80,6 +81,7 @@ def test_bench_under_torchrun_single_rank_rccl(built):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 1 and j["config"]["gathered_envs_with_a_finished_episode"] > 0
+    assert j["config"]["exchange_equals_plain_all_gather"] is True
     assert 0.0 < j["roofline"]["frac"] <= 1.0
     assert "rmav_allgather_stats_post" in j["config"]["parallelism"], j["config"]["parallelism"]
     # the torch.distributed exchange (the fallback) gives the same statistics
