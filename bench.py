@@ -228,17 +228,18 @@ def main():
         env = g.BatchedQuadrotor(kind, n, device=local_dev, seed=0, env_id_base=rank * n, auto_reset=True,
                                  track_episodes=True)
         gloo = use_dist and dist.get_backend() == "gloo"
-        exchange, exchange_kind = None, None
+        exchange, exchange_kind, native_abandoned = None, None, False
         if use_dist:
             # the collective behind the C ABI (RCCL from librmav's own stream, ~15 us of host time per post); every rank must
             # take the same path, so fall back together to the torch.distributed exchange if any rank cannot set it up
             ok = 0
             if not gloo and os.environ.get("RMAV_BENCH_EXCHANGE", "native") == "native":
-                try:
-                    exchange = NativeStatsExchange(env, n_total)
+                try:   # communicator + one whole exchange under a watchdog: a rank that is stuck falls back with the others
+                    exchange = NativeStatsExchange(env, n_total, connect_timeout_s=float(os.environ.get("RMAV_BENCH_CONNECT_TIMEOUT", "90")))
                     ok = 1
-                except Exception as e:  # pragma: no cover
+                except BaseException as e:  # pragma: no cover
                     print(f"[rank {rank}] native exchange unavailable: {e!r}", file=sys.stderr)
+                    native_abandoned = isinstance(e, TimeoutError)
                 flag = torch.tensor([ok], dtype=torch.int32, device=dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
@@ -522,6 +523,12 @@ def main():
             except Exception as e:  # pragma: no cover
                 line["cpu_baseline_python"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
+    if native_abandoned:   # a thread of this process is still inside RCCL: do not wait for it in any destructor
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if use_dist:
+            dist.barrier()
+        os._exit(0)
     if exchange is not None and hasattr(exchange, "close"):
         torch.cuda.synchronize()
         exchange.close()

@@ -81,18 +81,20 @@ struct rmav_env_s {
     size_t pinned_bytes;
 };
 
+constexpr int kExchangeDepth = 8;   // buffer pairs of the overlapped statistics exchange
 struct rmav_comm_s {
     uint32_t magic;
     int rank, world, device;
     ncclComm_t comm;
     // overlapped exchange: the collective runs on the communicator's own stream, double-buffered
     hipStream_t stream;
-    hipEvent_t ready[2], done[2];
-    bool used[2];
-    int32_t *send[2], *recv[2];
+    hipEvent_t ready[kExchangeDepth], done[kExchangeDepth];
+    bool used[kExchangeDepth];
+    int32_t *send[kExchangeDepth], *recv[kExchangeDepth];
+    int depth;         // buffer pairs in use (RMAV_EXCHANGE_DEPTH, 2 .. kExchangeDepth)
     uint32_t *flag;    // signal word (hipMallocSignalMemory): the compute stream publishes post numbers, the comm stream waits
     int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
-    int posts;         // number of posts so far (buffer of post i is i & 1)
+    int posts;         // number of posts so far (buffer pair of post i is i % depth)
 };
 
 namespace {
@@ -1217,8 +1219,22 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
         delete c;
         return fail(RMAV_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
     }
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+    // A high-priority stream: HIP multiplexes all streams of one priority onto a few hardware queues (GPU_MAX_HW_QUEUES,
+    // 4 by default) round-robin, and a process that also runs torch has dozens - when the communicator's stream lands on
+    // the compute stream's hardware queue their packets serialise (measured: a 131 072-env rollout 85 -> 108 us with the
+    // default mapping, 189 us with GPU_MAX_HW_QUEUES=8, 93 us with 2).  Priority levels have queues of their own.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    static const bool plain = [] { const char *e2 = getenv("RMAV_COMM_STREAM_PRIORITY"); return e2 && atoi(e2) == 0; }();
+    hipError_t e = plain ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)
+                         : hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
+    {
+        const char *ed = getenv("RMAV_EXCHANGE_DEPTH");
+        c->depth = ed ? atoi(ed) : kExchangeDepth;
+        if (c->depth < 2) c->depth = 2;
+        if (c->depth > kExchangeDepth) c->depth = kExchangeDepth;
+    }
+    for (int k = 0; k < kExchangeDepth && e == hipSuccess; ++k) {
         // device-scope release: these events only order streams of this GPU (RMAV_DBG_EVENT_FLAGS overrides, diagnostic)
         static const unsigned evf = [] {
             const char *e2 = getenv("RMAV_DBG_EVENT_FLAGS");
@@ -1235,7 +1251,7 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     // Hand-over from the compute stream to the communicator's stream without an event: hipEventRecord puts a barrier
     // packet into the COMPUTE stream (~8 us in front of the next rollout launch, measured); a one-thread kernel that
     // publishes the post number in a signal word, and hipStreamWaitValue32 on the communicator's stream, cost the
-    // compute stream one tiny launch.  Falls back to the event when the device cannot wait on memory.
+    // compute stream one tiny launch (hipStreamWriteValue32 in its place: +3 us per post, measured).  Falls back to the event when the device cannot wait on memory.
     int can_wait = 0;
     (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
     const char *e2 = getenv("RMAV_EXCHANGE_EVENTS");   // =1: hand over with events (diagnostic A/B)
@@ -1258,7 +1274,7 @@ int rmav_comm_destroy(rmav_comm c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     RcclApi *R = rccl();
     if (R && c->comm) (void)R->CommDestroy(c->comm);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < kExchangeDepth; ++k) {
         if (c->ready[k]) (void)hipEventDestroy(c->ready[k]);
         if (c->done[k]) (void)hipEventDestroy(c->done[k]);
         if (c->send[k]) (void)hipFree(c->send[k]);
@@ -1307,10 +1323,10 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     RcclApi *R = rccl();
     if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
-    if (cmax > c->cmax) {   // (re)allocate the two buffer pairs
+    if (cmax > c->cmax) {   // (re)allocate the buffer pairs
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < c->depth; ++k) {
             if (c->send[k]) (void)hipFree(c->send[k]);
             if (c->recv[k]) (void)hipFree(c->recv[k]);
             c->send[k] = c->recv[k] = nullptr;
@@ -1324,12 +1340,18 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
         }
         c->cmax = cmax;
     }
-    const int k = c->posts & 1;
-    // the gather that last used this buffer pair must have finished before the pack overwrites its send half
-    // (normally it finished long ago - the host sees that and nothing is inserted into the compute stream)
+    const int k = c->posts % c->depth;
+    // The gather that last used this buffer pair (`depth` posts ago) must have finished before the pack overwrites its
+    // send half.  In a GPU-bound loop the host runs far ahead of the device, so with two pairs that gather has usually not
+    // even started when the host gets here, and a device-side wait (hipStreamWaitEvent = a barrier packet in the COMPUTE
+    // stream) was inserted in front of nearly every pack: +8 us per rollout, measured.  So the HOST waits instead - back
+    // pressure that bounds its lead to `depth` rollouts (>= 0.5 ms of queued GPU work at depth 8) and puts nothing into
+    // the compute stream.  RMAV_EXCHANGE_DEVICE_WAIT=1: the device-side wait (diagnostic A/B).
     if (c->used[k] && hipEventQuery(c->done[k]) != hipSuccess) {
         (void)hipGetLastError();
-        HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
+        static const bool device_wait = [] { const char *e = getenv("RMAV_EXCHANGE_DEVICE_WAIT"); return e && atoi(e) == 1; }();
+        if (device_wait) HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
+        else HIP_TRY(hipEventSynchronize(c->done[k]));
     }
     hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
                        (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
@@ -1370,7 +1392,7 @@ int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, flo
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
     if (c->posts == 0 || cmax != c->cmax) return fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
-    const int k = (c->posts - 1) & 1;
+    const int k = (c->posts - 1) % c->depth;
     HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
                        (const int32_t *)c->recv[k], n_total, (int32_t)c->world, cmax, returns_out, lengths_out);

@@ -86,7 +86,9 @@ class EpisodeStatsExchange:
         self.on_gpu = self.device.type == "cuda"
         self.send = [torch.zeros(2 * self.cmax, dtype=torch.int32, device=self.device) for _ in range(2)]
         self.recv = [torch.empty(self.world * 2 * self.cmax, dtype=torch.int32, device=self.device) for _ in range(2)]
-        self.comm_stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
+        # high priority: a hardware queue of its own (streams of one priority share a few queues round-robin, and a
+        # collective's stream that lands on the compute stream's queue serialises with it)
+        self.comm_stream = torch.cuda.Stream(device=self.device, priority=-1) if self.on_gpu else None
         self.done_ev = [None, None]
         self._ready = [torch.cuda.Event(), torch.cuda.Event()] if self.on_gpu else None   # reused: no per-post allocation
         self._done = [torch.cuda.Event(), torch.cuda.Event()] if self.on_gpu else None
@@ -141,9 +143,13 @@ class NativeStatsExchange:
     ``rmav_allgather_stats_post / _result``: RCCL ``ncclAllGather`` on the communicator's own HIP stream, double
     buffered).  ``torch.distributed`` only carries the 128-byte RCCL unique id from rank 0 to the others.  About
     15 us of host time per post against ~100 us for ``all_gather_into_tensor`` behind Python, which matters when one
-    exchange follows every ~100 us rollout launch."""
+    exchange follows every ~100 us rollout launch.
 
-    def __init__(self, env, n_total: int, group=None):
+    ``connect_timeout_s``: create the communicator and run one complete exchange on a helper thread and give up
+    (``TimeoutError``; the communicator is abandoned, never destroyed) if that takes longer - a caller that can fall back
+    to ``EpisodeStatsExchange`` is then not stuck behind a collective that never completes."""
+
+    def __init__(self, env, n_total: int, group=None, connect_timeout_s: Optional[float] = None):
         import ctypes as C
 
         from . import _abi as A
@@ -169,9 +175,39 @@ class NativeStatsExchange:
         if err is not None or not any(raw):   # all-zero id = rank 0 could not create one: every rank raises
             raise RuntimeError(f"no RCCL unique id from rank 0 ({err!r})")
         self._comm = C.c_void_p()
-        A.check(L.rmav_comm_create(C.byref(self._comm), raw, self.rank, self.world, env.device))
+        self._abandoned = False
         self.ret = torch.empty(self.n_total, dtype=torch.float32, device=dev)
         self.len = torch.empty(self.n_total, dtype=torch.int32, device=dev)
+
+        def connect():
+            A.check(L.rmav_comm_create(C.byref(self._comm), raw, self.rank, self.world, env.device))
+            if connect_timeout_s is not None:   # one whole exchange before anybody relies on it
+                self.post()
+                self.result()
+                torch.cuda.synchronize(dev)
+
+        if connect_timeout_s is None:
+            connect()
+        else:
+            import threading
+
+            box = []
+
+            def target():
+                try:
+                    with torch.cuda.device(dev):
+                        connect()
+                except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+                    box.append(e)
+
+            th = threading.Thread(target=target, daemon=True)
+            th.start()
+            th.join(connect_timeout_s)
+            if th.is_alive():
+                self._abandoned = True
+                raise TimeoutError(f"the RCCL communicator / first exchange did not complete in {connect_timeout_s} s")
+            if box:
+                raise box[0]
 
     def post(self, env=None, **_):
         e = env if env is not None else self.env
@@ -184,9 +220,9 @@ class NativeStatsExchange:
         return self.ret, self.len
 
     def close(self):
-        if self._comm:
+        if self._comm and not self._abandoned:
             self._A.lib().rmav_comm_destroy(self._comm)
-            self._comm = None
+        self._comm = None
 
 
 def all_reduce_totals(totals: dict, device=None, group=None) -> dict:

@@ -7,6 +7,12 @@ import gym_reinmav_amd as g
 A = g._abi; L = A.lib()
 n, T, K = int(os.environ.get("N", "131072")), 64, 500
 dev = torch.device("cuda", 0)
+if os.environ.get("PROBE_PG") == "1":   # with torch's own NCCL process group alive in the process, like bench.py under torchrun
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    dist.barrier()
 st = torch.cuda.Stream(device=dev)
 with torch.cuda.stream(st):
     env = g.BatchedQuadrotor("quad3d", n, seed=0)
