@@ -290,10 +290,11 @@ int rmav_comm_destroy(rmav_comm c);
  * ncclAllGather over xGMI -> unpack); does not synchronise.  Needs RMAV_F_TRACK_EPISODES. */
 int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
 /* The same exchange in two halves, so that it overlaps the next rollout: _post packs this rank's payload on the
- * handle's stream (a stream-ordered snapshot) and runs the ncclAllGather on the communicator's OWN stream behind
- * an event (double-buffered: two exchanges may be in flight); _result makes the handle's stream wait for the most
- * recently posted gather and unpacks it.  rmav_allgather_stats = _post followed by _result.  ~15 us of host time
- * per post (one launch, two event records, one RCCL enqueue). */
+ * handle's stream (a stream-ordered snapshot) and runs the ncclAllGather on the communicator's OWN (high-priority)
+ * stream behind a signal word; up to eight exchanges may be in flight, and a ninth post blocks the HOST until the
+ * oldest one has finished (back pressure - nothing is ever inserted into the handle's stream).  _result makes the
+ * handle's stream wait for the most recently posted gather and unpacks it.  rmav_allgather_stats = _post followed
+ * by _result.  ~15 us of host time per post (two small launches, one event record, one RCCL enqueue). */
 int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
 int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
 /* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
