@@ -122,14 +122,23 @@ template <typename R> RMAV_HD void override_params(ParamsT<R> &p, double mass, d
 }
 
 // ---- Philox4x32-10 (counter RNG; stream layout documented in include/rmav.h) ----------------------
+// a ^ b ^ c: one v_bitop3_b32 (truth table 0x96) on gfx950 - hipcc leaves the two xors of a Philox round unfused, and the
+// random-action draw is the largest single block of the rollout's instruction stream (64 -> 44 vector instructions per call)
+RMAV_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
 RMAV_HD void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                            uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;
