@@ -849,7 +849,7 @@ __device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_
                       (uint32_t)(seed >> 32), r);
         float u[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) u[i] = rfma(2.0f, u01(r[i]), -1.0f);
+        for (int i = 0; i < 4; ++i) u[i] = rfma(1.0f / 8388608.0f, (float)(r[i] >> 8), -1.0f);
         // a needing lane with k set bits of m below it (k < 16) takes component c from lane 4k + c / 4, register c % 4
         const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         const bool mine = need && ((m >> lane) & 1ull) && k < 16u;
