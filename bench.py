@@ -284,8 +284,12 @@ def main():
                 } for _ in range(R)]
                 it = [0]
 
+                arm = exchange is not None and not gloo and os.environ.get("RMAV_BENCH_ARM", "1") == "1"
+
                 def run(k):
                     for _ in range(k):
+                        if arm and (it[0] + 1) % args.exchange_every == 0:   # this launch writes the exchange's snapshot itself
+                            exchange.arm(env)
                         env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
                                     want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
                         it[0] += 1

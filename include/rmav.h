@@ -296,6 +296,13 @@ int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *ret
  * handle's stream wait for the most recently posted gather and unpacks it.  rmav_allgather_stats = _post followed
  * by _result.  ~15 us of host time per post (two small launches, one event record, one RCCL enqueue). */
 int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
+/* Optional, BEFORE the rollout whose statistics the next _post will exchange: the next fused rmav_rollout /
+ * rmav_rollout_policy launch of `h` then writes the snapshot itself (every wavefront stores its envs' statistics into
+ * the exchange's send buffer and publishes an arrival word; the communicator's stream polls those), so that _post puts
+ * NOTHING into the handle's stream - no pack kernel, no signal kernel (~8 us per post at 131 072 envs).  Same snapshot,
+ * same result.  If no such launch happens between _arm and _post (single-step launches, a sliced launch), _post packs
+ * as usual.  One armed exchange per handle at a time; _post with the same communicator consumes it. */
+int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total);
 int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
 /* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
  * send_out i32 [2][cmax] (DEVICE) <- bit patterns of the per-env last returns, then the last lengths, zero padded

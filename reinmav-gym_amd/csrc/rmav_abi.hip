@@ -79,6 +79,15 @@ struct rmav_env_s {
     void *pinned;
     void *pinned_dev;
     size_t pinned_bytes;
+    // statistics exchange armed for the next fused rollout launch (rmav_allgather_stats_arm): where that launch's wavefronts
+    // snapshot their envs' statistics and publish their arrival; `fired` once a launch has taken it
+    struct {
+        bool armed, fired;
+        struct rmav_comm_s *comm;
+        int slot;
+        int64_t cmax;
+        uint32_t seq, expected;
+    } xchg;
 };
 
 constexpr int kExchangeDepth = 8;   // buffer pairs of the overlapped statistics exchange
@@ -92,6 +101,7 @@ struct rmav_comm_s {
     bool used[kExchangeDepth];
     int32_t *send[kExchangeDepth], *recv[kExchangeDepth];
     int depth;         // buffer pairs in use (RMAV_EXCHANGE_DEPTH, 2 .. kExchangeDepth)
+    uint32_t *arrive;  // arrival words of armed launches, one per wavefront: ceil(cmax / 32) of them
     uint32_t *flag;    // signal word (hipMallocSignalMemory): the compute stream publishes post numbers, the comm stream waits
     int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
     int posts;         // number of posts so far (buffer pair of post i is i % depth)
@@ -236,7 +246,18 @@ constexpr int64_t kEnvsPerCuSlot = 16384;   // 256 CUs x 64 envs: one pair per C
 constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches beyond the capacity: measured, see DESIGN.md
 
 template <int K, int MODE, int ST>
-int launch_rollout_kms(rmav_handle h, const RolloutArgs &a) {
+int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
+    RolloutArgs a = a_in;
+    // an armed statistics exchange rides on the first single-launch fused rollout after rmav_allgather_stats_arm
+    if (h->xchg.armed && !h->xchg.fired && a.slice_count == 0 && (a.flags & F_TRACK)) {
+        rmav_comm_s *c = h->xchg.comm;
+        a.xsend = c->send[h->xchg.slot];
+        a.xcmax = h->xchg.cmax;
+        a.xarrive = c->arrive;
+        a.xseq = h->xchg.seq;
+        h->xchg.expected = (uint32_t)(MODE == ACT_POLICY_F32M ? (h->n + 31) / 32 : (h->n + 63) / 64);
+        h->xchg.fired = true;
+    }
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
@@ -1281,6 +1302,7 @@ int rmav_comm_destroy(rmav_comm c) {
         if (c->recv[k]) (void)hipFree(c->recv[k]);
     }
     if (c->flag) (void)hipFree(c->flag);
+    if (c->arrive) (void)hipFree(c->arrive);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -1317,8 +1339,9 @@ int check_shard(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out) 
 }
 }  // namespace
 
-int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
-    CHECK_HANDLE(h);
+namespace {
+// Common front of _arm and _post: shard check, buffers, and the buffer pair of the next post (host-side back pressure).
+int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out, int *slot_out) {
     int64_t cmax = 0;
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     RcclApi *R = rccl();
@@ -1337,7 +1360,19 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
                 c->cmax = 0;
                 return fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
             }
+            // an armed launch writes only this rank's envs: the padding up to cmax stays zero from here on
+            HIP_TRY(hipMemsetAsync(c->send[k], 0, (size_t)(2 * cmax) * sizeof(int32_t), c->stream));
         }
+        if (c->arrive) (void)hipFree(c->arrive);
+        c->arrive = nullptr;
+        const size_t words = (size_t)((cmax + 31) / 32);
+        if (hipMalloc((void **)&c->arrive, words * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->cmax = 0;
+            return fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
+        }
+        HIP_TRY(hipMemsetAsync(c->arrive, 0, words * sizeof(uint32_t), c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->cmax = cmax;
     }
     const int k = c->posts % c->depth;
@@ -1353,17 +1388,61 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
         if (device_wait) HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
         else HIP_TRY(hipEventSynchronize(c->done[k]));
     }
-    hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
-    HIP_TRY(hipGetLastError());
-    if (c->flag) {
-        const uint32_t seq = (uint32_t)(c->posts + 1);
-        hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, h->stream, c->flag, seq);
+    *cmax_out = cmax;
+    *slot_out = k;
+    return RMAV_OK;
+}
+}  // namespace
+
+int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total) {
+    CHECK_HANDLE(h);
+    if (h->xchg.armed) return fail(RMAV_ERR_INVALID, "an exchange is already armed on this handle: post it first");
+    int64_t cmax = 0;
+    int k = 0;
+    if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) return rc;
+    h->xchg.armed = true;
+    h->xchg.fired = false;
+    h->xchg.comm = c;
+    h->xchg.slot = k;
+    h->xchg.cmax = cmax;
+    h->xchg.seq = (uint32_t)(c->posts + 1);
+    h->xchg.expected = 0;
+    return RMAV_OK;
+}
+
+int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
+    CHECK_HANDLE(h);
+    int64_t cmax = 0;
+    int k = 0;
+    RcclApi *R = rccl();
+    const bool armed = h->xchg.armed;
+    if (armed && h->xchg.comm != c) return fail(RMAV_ERR_INVALID, "the handle's armed exchange belongs to another communicator");
+    if (armed) {   // checked, allocated and back-pressured when it was armed
+        if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+        cmax = h->xchg.cmax;
+        k = h->xchg.slot;
+        h->xchg.armed = false;
+    } else if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) {
+        return rc;
+    }
+    if (armed && h->xchg.fired) {
+        // the rollout launch itself wrote the snapshot and its wavefronts' arrival words: nothing enters the compute stream
+        hipLaunchKernelGGL(k_wait_arrivals, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->arrive, h->xchg.expected,
+                           h->xchg.seq);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamWaitValue32(c->stream, c->flag, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
     } else {
-        HIP_TRY(hipEventRecord(c->ready[k], h->stream));
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
+        hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
+                           (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
+        HIP_TRY(hipGetLastError());
+        if (c->flag) {
+            const uint32_t seq = (uint32_t)(c->posts + 1);
+            hipLaunchKernelGGL(k_signal, dim3(1), dim3(1), 0, h->stream, c->flag, seq);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamWaitValue32(c->stream, c->flag, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        } else {
+            HIP_TRY(hipEventRecord(c->ready[k], h->stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
+        }
     }
     static const int dbg = [] { const char *e = getenv("RMAV_DBG_EXCHANGE"); return e ? atoi(e) : 0; }();
     if (dbg == 1) {   // diagnostic: no collective at all

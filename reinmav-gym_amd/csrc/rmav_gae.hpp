@@ -146,6 +146,19 @@ __global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ la
 __global__ void k_signal(uint32_t *flag, uint32_t seq) {
     __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// The communicator's stream waits here until every wavefront of the armed rollout launch has published `seq` (or a later
+// post's) in its arrival word: one workgroup polling `count` words with agent-scope loads.  hipStreamWaitValue32 is a
+// spinning one-wavefront kernel of the runtime as well (__amd_rocclr_streamOpsWait in the kernel trace); this one waits
+// for the rollout kernel's own wavefronts, so the compute stream needs no pack and no signal kernel.
+__global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, uint32_t count, uint32_t seq) {
+    for (;;) {
+        int ok = 1;
+        for (uint32_t i = threadIdx.x; i < count; i += 256u)
+            ok &= (int32_t)(__hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0;
+        if (__syncthreads_and(ok)) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
 // diagnostic stand-in for a collective's kernel (RMAV_DBG_EXCHANGE=3): workgroups that hold their CU slots - threads,
 // registers and `extern` LDS - for `cycles` ticks of the 100 MHz wall clock without touching memory, like a ring all-gather waiting for
 // its peers.  Used to measure how the rollout kernels tolerate a co-resident communication kernel on ONE GPU.

@@ -125,6 +125,14 @@ struct RolloutArgs {
     // this launch covers envs [slice_first, slice_first + slice_count) of the handle's N (slice_count = 0: all of them);
     // trajectory pitches stay N.  slice_first is a multiple of 64.
     uint32_t slice_first, slice_count;
+    // statistics exchange armed for this launch (rmav_allgather_stats_arm), nullptr otherwise: every wavefront snapshots
+    // its envs' last-episode statistics into the exchange's send buffer [2][xcmax] and then publishes xseq in its word of
+    // xarrive - the communicator's stream polls those words (k_wait_arrivals), so the compute stream carries no pack or
+    // signal kernel at all
+    int32_t *xsend;
+    int64_t xcmax;
+    uint32_t *xarrive;
+    uint32_t xseq;
 };
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
@@ -820,6 +828,23 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 atomicAdd(&slot->return_sum, (double)wr);
             }
         }
+    }
+
+    if (a.xsend) {   // wave-uniform.  Snapshot for the statistics exchange, then this wavefront's arrival word.
+        // The loads see this lane's own stores of the step loop (same address, same lane: program order); the stores are
+        // agent-scope (written through to the level the other XCDs' wavefronts and the next kernel read from), and
+        // vmcnt(0) = they have been acknowledged there before the arrival word goes out.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (valid && !(HALF && (threadIdx.x & 32u))) {
+            const float lr = a.last_ret[li];
+            const int32_t ll = a.last_len[li];
+            __hip_atomic_store(a.xsend + li, __builtin_bit_cast(int32_t, lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.xsend + a.xcmax + li, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // one word per wavefront that owns envs (its lane 0 owns the first of them): 64 envs each, 32 in the fp32-MFMA mode
+        if ((threadIdx.x & 63u) == 0 && valid)
+            __hip_atomic_store(a.xarrive + (HALF ? (ge >> 5) : (ge >> 6)), a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

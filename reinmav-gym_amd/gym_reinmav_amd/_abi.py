@@ -100,6 +100,7 @@ PROTOTYPES = {
     "rmav_comm_destroy": (C.c_int, [C.c_void_p]),
     "rmav_allgather_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
     "rmav_allgather_stats_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
+    "rmav_allgather_stats_arm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rmav_allgather_stats_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
     "rmav_pack_stats": (C.c_int, [C.c_void_p, C.c_int64, _vp]),
     "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),

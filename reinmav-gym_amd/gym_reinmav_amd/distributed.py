@@ -95,6 +95,9 @@ class EpisodeStatsExchange:
         self.i = 0
         self.last = None
 
+    def arm(self, env=None):
+        """Interface parity with NativeStatsExchange (nothing to prepare on this path)."""
+
     def post(self, last_return=None, last_length=None, env=None):
         """Either the two per-env tensors, or ``env=`` a BatchedQuadrotor shard (packed by one launch of its own)."""
         k = self.i & 1
@@ -208,6 +211,12 @@ class NativeStatsExchange:
                 raise TimeoutError(f"the RCCL communicator / first exchange did not complete in {connect_timeout_s} s")
             if box:
                 raise box[0]
+
+    def arm(self, env=None):
+        """Call BEFORE the rollout whose statistics the next post() exchanges: that launch then writes the snapshot itself
+        and post() adds nothing to the env's stream (rmav_allgather_stats_arm)."""
+        e = env if env is not None else self.env
+        self._A.check(self._A.lib().rmav_allgather_stats_arm(e._h, self._comm, self.n_total))
 
     def post(self, env=None, **_):
         e = env if env is not None else self.env

@@ -156,6 +156,72 @@ print('rccl abi ok')
     assert r.returncode == 0 and "rccl abi ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
+def test_armed_exchange_equals_the_packed_one_single_rank(G):
+    """rmav_allgather_stats_arm: the rollout launch writes the exchange's snapshot itself (every kernel family: one and
+    two wavefronts, controller, caller actions, the three in-kernel actors; ragged batch sizes), _post adds nothing to the
+    handle's stream, and the gathered arrays equal the handle's statistics after THAT launch - also when the next
+    rollout is already queued behind it.  Launches that cannot carry it (single steps) fall back to the pack."""
+    code = f"""
+import ctypes as C, sys
+sys.path.insert(0, {os.path.join(ROOT, 'reinmav-gym_amd')!r})
+import numpy as np, torch
+import gym_reinmav_amd as g
+from gym_reinmav_amd.ppo import MlpPolicy, FusedPolicyCollector
+A = g._abi
+L = A.lib()
+uid = (C.c_char * A.COMM_ID_BYTES)()
+def gathered(env, comm, n):
+    ret = torch.empty(n, dtype=torch.float32, device='cuda'); ln = torch.empty(n, dtype=torch.int32, device='cuda')
+    A.check(L.rmav_allgather_stats_result(env._h, comm, n, C.c_void_p(ret.data_ptr()), C.c_void_p(ln.data_ptr())))
+    env.sync()
+    return ret.cpu().numpy(), ln.cpu().numpy()
+checked = 0
+for kind, n in (('quad3d', 4099), ('quad3d', 200000), ('quad2d_sl', 777), ('quad3d_sl', 8192)):
+    env = g.BatchedQuadrotor(kind, n, seed=2)
+    A.check(L.rmav_comm_unique_id(uid)); comm = C.c_void_p(); A.check(L.rmav_comm_create(C.byref(comm), uid, 0, 1, 0))
+    acts = torch.empty((16, env.nA, n), device='cuda').uniform_(0, 10)
+    pol = MlpPolicy(env.nS, env.nA).cuda()
+    launches = [lambda: env.rollout(64, mode='random', want=(), device_out=True),
+                lambda: env.rollout(16, mode='controller', want=(), device_out=True),
+                lambda: env.rollout(16, mode='buffer', actions=acts, want=(), device_out=True),
+                lambda: env.rollout(4, mode='random', want=(), device_out=True)]       # n_steps < 8: the one-wavefront kernel
+    if n <= 8192:
+        for kw in (dict(f32_mfma=False), dict(bf16_mfma=True), dict(f32_mfma=True)):
+            col = FusedPolicyCollector(env, pol, 8, **kw)
+            launches.append(col.collect)
+    for fn in launches:
+        A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+        assert L.rmav_allgather_stats_arm(env._h, comm, n) == A.ERR_INVALID          # one at a time
+        fn()
+        eb = env.episode_buffers()                                                     # statistics after THIS launch
+        A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+        env.rollout(8, mode='random', want=(), device_out=True)                        # the next rollout, queued behind it
+        r, l = gathered(env, comm, n)
+        assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length']), (kind, n)
+        checked += 1
+    # a single-step launch cannot carry it: _post packs as before
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+    env.step(np.zeros((n, env.nA), np.float32))
+    eb = env.episode_buffers()
+    A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+    r, l = gathered(env, comm, n)
+    assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
+    assert (eb['last_length'] > 0).any()
+    # more posts than buffer pairs, armed and plain mixed
+    for i in range(20):
+        if i % 3: A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+        env.rollout(8, mode='random', want=(), device_out=True)
+        A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+    eb = env.episode_buffers()
+    r, l = gathered(env, comm, n)
+    assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
+    A.check(L.rmav_comm_destroy(comm)); env.close()
+print('armed exchange ok', checked)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "armed exchange ok" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
 def test_pack_stats_is_the_allgather_payload(G):
     import torch
 
