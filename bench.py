@@ -380,6 +380,7 @@ def main():
         if use_dist and exchange is not None and args.mode == "rollout":
             # outside the timed region: one more exchange of the final per-env statistics, checked element by element
             # against a plain torch.distributed all-gather of the same buffers (global env order = rank order here)
+            during = [t.clone() for t in gathered] if gathered is not None else None   # the timed region's last exchange
             eb = env.episode_buffers(device_out=not gloo)
             mine = [torch.as_tensor(eb["last_return"]), torch.as_tensor(eb["last_length"])]
             if gloo:
@@ -391,8 +392,11 @@ def main():
             ref = [torch.empty(n_total, dtype=t.dtype, device=t.device) for t in mine]
             for r_, m_ in zip(ref, mine):
                 dist.all_gather_into_tensor(r_, m_.contiguous())
-            exchange_check = bool(torch.equal(got[0].to(ref[0].device).view(torch.int32), ref[0].view(torch.int32))
-                                  and torch.equal(got[1].to(ref[1].device), ref[1]))
+            same = lambda g_: bool(torch.equal(g_[0].to(ref[0].device).view(torch.int32), ref[0].view(torch.int32))  # noqa: E731
+                                   and torch.equal(g_[1].to(ref[1].device), ref[1]))
+            exchange_check = same(got)
+            if during is not None and args.exchange_every == 1:   # posted after the last launch: the same statistics
+                exchange_check = exchange_check and same(during)
             okf = torch.tensor([int(exchange_check)], dtype=torch.int32, device="cpu" if gloo else dev)
             dist.all_reduce(okf, op=dist.ReduceOp.MIN)   # rank 0 reports for every rank
             if not exchange_check:
