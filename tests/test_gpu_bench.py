@@ -41,6 +41,8 @@ def test_bench_single_process_line(built):
     assert om["policy_rollout"]["fp32_mfma"]["env_steps_per_s"] > om["policy_rollout"]["fp32_valu"]["env_steps_per_s"] > 0
     assert om["policy_rollout"]["bf16_mfma"]["env_steps_per_s"] > 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["cores"] == 1
+    ds = j["device_state"]                                       # socket power / cap / shader clock while the headline ran
+    assert ds["samples"] == 0 or (0 < ds["power_w_mean"] <= ds["power_w_max"] and ds["sclk_mhz_mean"] > 0)
 
 
 @pytest.mark.timeout(900)

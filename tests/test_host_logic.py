@@ -86,3 +86,23 @@ def test_bench_byte_accounting():
     assert b.fused_bytes_per_launch(65536, 64, 10, 4) == 65536 * (64 * 61 + 104)
     assert b.fused_bytes_per_launch(1, 1, 16, 4) == 4 * 21 + 1 + 8 * 16 + 24
     assert b.HBM_PEAK_GBS == 8000.0
+
+
+def test_bench_device_sampler_summary():
+    """bench.py's device_state: only samples taken while the GPU was busy count; unreadable sysfs gives None fields."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    s = b.DeviceSampler(0)                      # no GPU here: nothing to read, nothing started
+    with s:
+        pass
+    assert s.summary()["power_w_mean"] is None and s.summary()["samples"] == 0
+    s.samples = [(250.0, 100.0), (1300.0, 2300.0), (1400.0, 2200.0), (260.0, 90.0)]
+    s.cap = 1400.0
+    out = s.summary()
+    assert out["samples"] == 2 and out["power_w_mean"] == 1350.0 and out["power_w_max"] == 1400.0
+    assert out["sclk_mhz_mean"] == 2250 and out["power_cap_w"] == 1400.0
