@@ -295,7 +295,8 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         using ST_ = SplitTile<NS, NA, DRAWS>;
         // The integrator's dependent chain is the critical path: issue priority 1 for it where that measured faster (same box,
         // two repetitions: quadrotor2d at 65 536 envs 36.9 -> 35.4 us, quadrotor3d at 131 072 envs 92.0 -> 90.5; NOT quadrotor3d
-        // with one pair per SIMD: 44.4 -> 44.8, so the 3-D kinds get it only from 6 pairs per workgroup up).
+        // with one pair per SIMD: 44.4 -> 44.8, so the 3-D kinds get it only from 6 pairs per workgroup up; priority for the MEMORY
+        // wavefront instead: 43.2 -> 45.0).
         if (!split_helper && (K == QUAD2D || K == QUAD2D_SL || split_g >= 6u)) __builtin_amdgcn_s_setprio(1);
         if (split_helper) {
             const uint64_t env_id = a.env_base + (uint64_t)li;
