@@ -309,7 +309,14 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
     const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
     if (forced == 0) return false;
     if (h->n <= cap) return true;
-    if (slice_forced == 1 || (slice_forced != 0 && kSliceByDefault)) {
+    // Two rounds of the two-wavefront kernel - two launches over balanced halves of the env range - beat one launch of the
+    // one-wavefront kernel when both halves (nearly) fill the machine: random-action 3-D kinds, 1.75 .. 2 x the capacity
+    // (profiles/r02/slice_two_rounds.md: quadrotor3d 262 144 envs 190.7 -> 160.3 us, slung load = BASELINE C4 271.5 -> 252.6 on a
+    // fast box, 292 -> 249 on a slow one).  Smaller second halves, more than two rounds, the 2-D kinds and the
+    // controller-driven rollouts measured equal or slower, so they stay on one launch.
+    const bool two_rounds = draws && (h->kind == RMAV_QUAD3D || h->kind == RMAV_QUAD3D_SL) && h->n <= 2 * cap &&
+                            4 * h->n >= 7 * cap;
+    if (slice_forced == 1 || (slice_forced != 0 && (kSliceByDefault || two_rounds))) {
         *slices = (int)((h->n + cap - 1) / cap);
         return true;
     }

@@ -65,6 +65,7 @@ print("## PMC passes (per-dispatch values of the hot-path kernel, warm-up dispat
 print("| run | counter | dispatches | mean KiB per dispatch |")
 print("|---|---|---|---|")
 vals = {}
+cover = {}
 for d in sorted(os.listdir(root)):
     if not d.startswith("pmc_") or not os.path.isdir(os.path.join(root, d)):
         continue
@@ -77,6 +78,9 @@ for d in sorted(os.listdir(root)):
         if not any(k in r.get("Kernel_Name", "") for k in KERNELS):
             continue
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        # envs one dispatch covers: the two-wavefront kernels (k_rollout<K, 5 | 6, *>) run 128 threads per 64 envs
+        two = any(t in r["Kernel_Name"] for t in (", 5, ", ", 6, "))
+        cover[d[4:].rsplit("_", 2)[0]] = int(r["Grid_Size"]) // (2 if two else 1)
     for c, v in acc.items():
         v = v[len(v) // 3:]   # drop the warm-up third (first-touch traffic)
         m = sum(v) / max(1, len(v))
@@ -103,10 +107,17 @@ for d in traces:
     j = bench_line(d)
     if f_ is None or w_ is None or not j:
         continue
-    b = (fcorr * f_ + wcorr * w_) * 1024.0
+    # a batch beyond the two-wavefront kernel's capacity may run as several dispatches per bench launch (two rounds)
+    per_launch = max(1, round(j["config"]["envs_per_gpu"] / cover[name])) if cover.get(name) else 1
+    b = (fcorr * f_ + wcorr * w_) * 1024.0 * per_launch
     need = j["roofline"]["bytes_per_launch"]
     us = avg_us.get(d)
-    print(f"| {name} | {b / 1e6:.1f} MB | {need / 1e6:.1f} MB | {b / need:.3f} | {us:.2f} | {b / us / 1e6:.2f} |" if us else f"| {name} | {b/1e6:.1f} MB | {need/1e6:.1f} MB | {b/need:.3f} | - | - |")
+    if us and per_launch > 1:
+        us *= per_launch
+        name_note = f" ({per_launch} dispatches per launch)"
+    else:
+        name_note = ""
+    print(f"| {name}{name_note} | {b / 1e6:.1f} MB | {need / 1e6:.1f} MB | {b / need:.3f} | {us:.2f} | {b / us / 1e6:.2f} |" if us else f"| {name} | {b/1e6:.1f} MB | {need/1e6:.1f} MB | {b/need:.3f} | - | - |")
     c = j["config"]
     key = (f"{c['kind']}:{c['mode']}:{c['env_steps_per_launch_per_env']}:{c['envs_per_gpu']}:"
            f"{'inplace' if (c['trajectory_ring'] == 1 or c['mode'] == 'step') else 'ring'}:{c['actions']}:{c['trajectory_layout']}")
