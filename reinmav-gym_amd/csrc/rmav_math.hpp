@@ -275,8 +275,7 @@ template <> struct Env<QUAD3D_SL> {
         const R b[3] = {bf[0], bf[1], bf[2]};
         const R tv[3] = {lp[0] - pos[0], lp[1] - pos[1], lp[2] - pos[2]};     // :101
         const R dd = rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2]));
-        const R d = root(dd);
-        const bool taut = d >= p.L;                                           // :104
+        const bool taut = dd >= p.L * p.L;                                    // :104  |tv| >= L, without the root
         const R k = thrust * p.inv_mass;
         R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};                 // :118 / :140
         R la[3] = {R(0), R(0), -p.g};                                         // :134 slack: a_l = g
@@ -291,9 +290,8 @@ template <> struct Env<QUAD3D_SL> {
             la[0] = f * u[0];
             la[1] = f * u[1];
             la[2] = rfma(f, u[2], -p.g);
-            // :115 T = m_l * |a_l - g| * u ;  a_l - g = f*u  (exactly, before rounding)
-            const R ag[3] = {la[0], la[1], la[2] + p.g};
-            const R tn = p.load_mass * root(rfma(ag[0], ag[0], rfma(ag[1], ag[1], ag[2] * ag[2])));
+            // :115 T = m_l * |a_l - g| * u ;  a_l - g = f*u with |u| = 1, so the norm is |f| (to ~1e-15; no root needed)
+            const R tn = p.load_mass * rabs(f);
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);   // :118 + T/mass
         }
@@ -325,10 +323,11 @@ template <> struct Env<QUAD3D_SL> {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) s[3 + i] = qof[i];
-        const R nlp = root(rfma(lp[0], lp[0], rfma(lp[1], lp[1], lp[2] * lp[2])));
-        const R nv = root(rfma(vel[0], vel[0], rfma(vel[1], vel[1], vel[2] * vel[2])));
-        done = (nlp > p.pos_limit) || (nv > p.vel_limit);   // :149-153 load position, quad velocity
-        dist = (float)nlp;                                  // :156 reward = -|load_pos|
+        // the two norms of the termination test and the reward: fp32, from the stored state, as in Quadrotor3D
+        const float nlp = root(rfma(s[10], s[10], rfma(s[11], s[11], s[12] * s[12])));
+        const float nv = root(rfma(s[7], s[7], rfma(s[8], s[8], s[9] * s[9])));
+        done = (nlp > (float)p.pos_limit) || (nv > (float)p.vel_limit);   // :149-153 load position, quad velocity
+        dist = nlp;                                                        // :156 reward = -|load_pos|
     }
 };
 
@@ -376,8 +375,7 @@ template <> struct Env<QUAD2D_SL> {
         const R dir[2] = {-(R)sn, (R)cs};
         const R tv[2] = {lp[0] - pos[0], lp[1] - pos[1]};         // :92
         const R dd = rfma(tv[0], tv[0], tv[1] * tv[1]);
-        const R d = root(dd);
-        const bool taut = d >= p.L;                               // :95
+        const bool taut = dd >= p.L * p.L;                        // :95  |tv| >= L, without the root
         const R k = thrust * p.inv_mass;
         R acc[2] = {k * dir[0], rfma(k, dir[1], -p.g)};           // :107 / :128
         R la[2] = {R(0), -p.g};                                   // :123
@@ -389,8 +387,7 @@ template <> struct Env<QUAD2D_SL> {
             const R f = sc * p.inv_mtot;                          // :98
             la[0] = f * u[0];
             la[1] = rfma(f, u[1], -p.g);
-            const R ag[2] = {la[0], la[1] + p.g};
-            const R tn = p.load_mass * root(rfma(ag[0], ag[0], ag[1] * ag[1]));   // :102
+            const R tn = p.load_mass * rabs(f);                   // :102 |a_l - g| = |f u| = |f|
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);
         }
@@ -417,10 +414,10 @@ template <> struct Env<QUAD2D_SL> {
         s[3] = (float)vel[0]; s[4] = (float)vel[1];
         s[5] = (float)lp[0];  s[6] = (float)lp[1];
         s[7] = (float)lv[0];  s[8] = (float)lv[1];
-        const R nlp = root(rfma(lp[0], lp[0], lp[1] * lp[1]));
-        const R nlv = root(rfma(lv[0], lv[0], lv[1] * lv[1]));
-        done = (nlp > p.pos_limit) || (nlv > p.vel_limit);        // :136-140 load pos, load vel
-        dist = (float)root(rfma(pos[0], pos[0], pos[1] * pos[1]));   // :143 reward = -|quad pos|
+        const float nlp = root(rfma(s[5], s[5], s[6] * s[6]));    // fp32 norms of the stored state, as in Quadrotor2D
+        const float nlv = root(rfma(s[7], s[7], s[8] * s[8]));
+        done = (nlp > (float)p.pos_limit) || (nlv > (float)p.vel_limit);   // :136-140 load pos, load vel
+        dist = root(rfma(s[0], s[0], s[1] * s[1]));               // :143 reward = -|quad pos|
     }
 };
 
