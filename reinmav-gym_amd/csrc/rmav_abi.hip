@@ -310,11 +310,12 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
     if (forced == 0) return false;
     if (h->n <= cap) return true;
     // Two rounds of the two-wavefront kernel - two launches over balanced halves of the env range - beat one launch of the
-    // one-wavefront kernel when both halves (nearly) fill the machine: random-action 3-D kinds, 1.75 .. 2 x the capacity
-    // (profiles/r02/slice_two_rounds.md: quadrotor3d 262 144 envs 190.7 -> 160.3 us, slung load = BASELINE C4 271.5 -> 252.6 on a
-    // fast box, 292 -> 249 on a slow one).  Smaller second halves, more than two rounds, the 2-D kinds and the
+    // one-wavefront kernel for the slung-load kinds (fp64 integrator: the one-wavefront kernel holds only 3-4 of them per SIMD)
+    // when both halves (nearly) fill the machine, 1.75 .. 2 x the capacity, random actions (profiles/r02/slice_two_rounds.md:
+    // BASELINE C4 = quadrotor3d-slungload at 262 144 envs 269-292 -> 249-252 us, quadrotor2d-slungload 172 -> 158).  Smaller
+    // second halves, more than two rounds, the plain kinds (quadrotor3d: +-4 %, quadrotor2d: slower) and the
     // controller-driven rollouts measured equal or slower, so they stay on one launch.
-    const bool two_rounds = draws && (h->kind == RMAV_QUAD3D || h->kind == RMAV_QUAD3D_SL) && h->n <= 2 * cap &&
+    const bool two_rounds = draws && (h->kind == RMAV_QUAD3D_SL || h->kind == RMAV_QUAD2D_SL) && h->n <= 2 * cap &&
                             4 * h->n >= 7 * cap;
     if (slice_forced == 1 || (slice_forced != 0 && (kSliceByDefault || two_rounds))) {
         *slices = (int)((h->n + cap - 1) / cap);
