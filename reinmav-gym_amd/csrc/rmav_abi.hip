@@ -1425,8 +1425,10 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     RcclApi *R = rccl();
     const bool armed = h->xchg.armed;
     if (armed && h->xchg.comm != c) return fail(RMAV_ERR_INVALID, "the handle's armed exchange belongs to another communicator");
-    if (armed) {   // checked, allocated and back-pressured when it was armed
+    if (armed) {   // allocated and back-pressured when it was armed
         if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+        if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
+        if (cmax != h->xchg.cmax) return fail(RMAV_ERR_INVALID, "n_total differs from the armed exchange's");
         cmax = h->xchg.cmax;
         k = h->xchg.slot;
         h->xchg.armed = false;
