@@ -30,6 +30,38 @@ import torch.distributed as dist
 from .core import BatchedQuadrotor
 
 
+class _LinearFM(torch.autograd.Function):
+    """``W @ x + b[:, None]`` on feature-major activations ``x [in, B]`` with a weight gradient that suits the learner's
+    shapes.  ``dW = dy @ x^T`` is a 64 x 64 result reduced over B = 524 288 samples: the BLAS library's pick for that
+    long-K product ran 355 us per call - 45 % of a PPO iteration at 65 536 envs x 32 steps.  Cut into chunks of
+    ``CHUNK`` columns it is a batched 64 x 64 x CHUNK product over hundreds of workgroups plus a small sum."""
+
+    CHUNK = 8192
+    _ones: dict = {}
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias[:, None], weight, x)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gx = weight.t() @ gy if ctx.needs_input_grad[0] else None
+        B, C = x.shape[1], _LinearFM.CHUNK
+        if B % C == 0 and B > C:
+            nb = B // C
+            gw = torch.bmm(gy.view(gy.shape[0], nb, C).transpose(0, 1),            # [nb, out, C]
+                           x.view(x.shape[0], nb, C).permute(1, 2, 0)).sum(0)       # [nb, C, in] -> [out, in]
+        else:
+            gw = gy @ x.t()
+        # bias gradient as a matrix-vector product with ones (the generic row reduction ran at 2.7 TB/s)
+        ones = _LinearFM._ones.get((B, gy.device))
+        if ones is None:
+            ones = _LinearFM._ones[(B, gy.device)] = torch.ones(B, dtype=gy.dtype, device=gy.device)
+        return gx, gw, torch.mv(gy, ones)
+
+
 class MlpPolicy(torch.nn.Module):
     """baselines ``mlp`` (2 x 64 tanh) Gaussian policy + separate value net, in feature-major form."""
 
@@ -47,7 +79,8 @@ class MlpPolicy(torch.nn.Module):
     @staticmethod
     def _mlp(net, x):  # x [in, N] -> [out, N]
         for i, lin in enumerate(net):
-            x = torch.addmm(lin.bias[:, None], lin.weight, x)
+            x = (_LinearFM.apply(x, lin.weight, lin.bias) if torch.is_grad_enabled() and x.is_cuda
+                 else torch.addmm(lin.bias[:, None], lin.weight, x))
             if i < 2:
                 x = torch.tanh(x)
         return x

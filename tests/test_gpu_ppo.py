@@ -63,6 +63,44 @@ def test_rollout_collector_matches_oracle(G, graph):
     env.close()
 
 
+def test_learner_linear_gradients_equal_autograd(G):
+    """_LinearFM (chunked long-K weight gradient, matrix-vector bias gradient) vs plain addmm under autograd."""
+    import torch
+    from gym_reinmav_amd.ppo import MlpPolicy, _LinearFM
+
+    torch.manual_seed(1)
+    for n_in, n_out, B in ((10, 64, 4 * _LinearFM.CHUNK), (64, 64, 2 * _LinearFM.CHUNK), (64, 4, 12345)):
+        x = torch.randn(n_in, B, device="cuda", requires_grad=True)
+        w = torch.randn(n_out, n_in, device="cuda", requires_grad=True)
+        b = torch.randn(n_out, device="cuda", requires_grad=True)
+        g = torch.randn(n_out, B, device="cuda")
+        _LinearFM.apply(x, w, b).backward(g)
+        got = [t.grad.clone() for t in (x, w, b)]
+        for t in (x, w, b):
+            t.grad = None
+        torch.addmm(b[:, None], w, x).backward(g)
+        for a_, r_ in zip(got, (x.grad, w.grad, b.grad)):
+            assert torch.allclose(a_, r_, rtol=2e-4, atol=2e-4 * float(r_.abs().max())), (n_in, n_out, B)
+    # and through the whole policy: same loss gradients with and without it
+    pol = MlpPolicy(10, 4).cuda()
+    obs = torch.randn(10, 2 * _LinearFM.CHUNK, device="cuda")
+    mean, v = pol(obs)
+    (mean.square().mean() + v.square().mean()).backward()
+    g1 = [p.grad.clone() for p in pol.parameters() if p.grad is not None]
+    pol.zero_grad()
+    orig = _LinearFM.apply
+    try:
+        _LinearFM.apply = staticmethod(lambda x, w, b: torch.addmm(b[:, None], w, x))
+        mean, v = pol(obs)
+        (mean.square().mean() + v.square().mean()).backward()
+    finally:
+        _LinearFM.apply = orig
+    g2 = [p.grad for p in pol.parameters() if p.grad is not None]
+    assert len(g1) == len(g2) > 0
+    for a_, r_ in zip(g1, g2):
+        assert torch.allclose(a_, r_, rtol=2e-4, atol=2e-5 * float(r_.abs().max()) + 1e-9)
+
+
 def test_ppo_learner_runs_and_fits_values(G):
     import torch
     from gym_reinmav_amd.ppo import PPO, MlpPolicy, RolloutCollector
