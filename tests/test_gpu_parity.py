@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): |d| <= 1e-6 * max(1, |y_ref|) on state and rewar
 fp32-representable (state, action); `done` exact except when a terminating norm is within 1e-5 of its
 limit; RNG-derived values (reset states, random actions) bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,7 @@ import oracle as O
 from util import BOX, CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, random_cases, scaled_err
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -200,6 +203,44 @@ def test_fused_rollout_equals_single_steps(G, kind, mode):
     for key in eb0:
         assert np.array_equal(eb0[key], eb1[key]), key
     assert k0 == k1 == T
+
+
+@pytest.mark.parametrize("kind,n", [("quad3d_sl", 235931), ("quad2d_sl", 262144), ("quad3d", 131072 + 77)])
+def test_kernel_selection_variants_give_the_same_bits(built, kind, n):
+    """One launch of the one-wavefront kernel, the two-wavefront kernel forced, and two rounds of it over balanced halves
+    (the default for random-action slung-load batches of 1.75-2 x the capacity) write the same trajectory, state, reset
+    counters and episode statistics - ragged sizes included.  The selection is read from the environment once per process,
+    hence the subprocesses; each prints a digest."""
+    import subprocess, sys
+
+    code = f"""
+import hashlib, sys
+sys.path.insert(0, {os.path.join(ROOT, 'reinmav-gym_amd')!r})
+import numpy as np
+import gym_reinmav_amd as g
+env = g.BatchedQuadrotor({kind!r}, {n}, seed=5, auto_reset=True, track_episodes=True)
+h = hashlib.sha256()
+for _ in range(2):
+    tr = env.rollout(24, mode='random', layout='soa', want=('actions', 'obs', 'rew', 'done'))
+    for k in ('actions', 'obs', 'rew', 'done'):
+        h.update(np.ascontiguousarray(tr[k]).tobytes())
+for a in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
+    h.update(np.ascontiguousarray(a).tobytes())
+eb = env.episode_buffers()
+for k in sorted(eb):
+    h.update(np.ascontiguousarray(eb[k]).tobytes())
+t = env.episode_totals()
+print('DIGEST', h.hexdigest(), t['episodes'], t['length_sum'])
+"""
+    digests = {}
+    for name, extra in (("default", {}), ("one wavefront", {"RMAV_SPLIT": "0", "RMAV_SLICE": "0"}),
+                        ("two wavefronts, one launch", {"RMAV_SPLIT": "1", "RMAV_SLICE": "0"}),
+                        ("two wavefronts, sliced", {"RMAV_SLICE": "1"})):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
+        assert r.returncode == 0 and line, (name, r.stdout[-1500:], r.stderr[-1500:])
+        digests[name] = line[0]
+    assert len(set(digests.values())) == 1, digests
 
 
 @pytest.mark.parametrize("kind", KINDS)
