@@ -223,6 +223,11 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
         // measured (profiles/r01/layout_sweep.md): pays from 131 072 envs x 64 steps (512 MB), costs 10-15 % at 65 536 (256 MB)
         return (a.obs_out && (bytes >= 448.0e6 || forced == ST_AOS_LDS)) ? ST_AOS_LDS : ST_WRITE_THROUGH;
     }
+    // Feature-major columns are 4 N bytes apart: unless N is a multiple of 16 they start off a 64-byte line, every wavefront's
+    // 256-byte store ends in partial lines, and only the write-back L2 can merge them with the neighbouring wavefront's part -
+    // write-through / non-temporal stores send the fragments on (same box: 65 599 envs 100.4 us per launch, write-back 67.7;
+    // 131 071: 200.9 -> 116.5; 1 048 575: 1700 -> 1564; the aligned sizes next to them: 48.8, 90.8, 730).
+    if ((h->n & 15) != 0) return ST_DEFAULT;
     if (split) return ST_WRITE_THROUGH;
     return bytes <= 192.0e6 ? ST_WRITE_THROUGH : ST_STREAM;
 }
