@@ -210,7 +210,7 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0 && forced <= 2 && !(a.flags & F_AOS)) return forced;
-    if (a.n_steps < 8) return ST_DEFAULT;
+    if (a.n_steps < 8 && !split) return ST_DEFAULT;
     double per_step = 0.0;
     if (a.act_out) per_step += 4.0 * kActionDim[h->kind];
     if (a.obs_out) per_step += 4.0 * kStateDim[h->kind];
@@ -310,7 +310,11 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
         return e ? atoi(e) : -1;
     }();
     *slices = 1;
-    if (a.n_steps < 8 || h->kind > RMAV_QUAD3D_SL) return false;
+    static const int min_steps = [] {
+        const char *e = getenv("RMAV_SPLIT_MIN_STEPS");
+        return e ? atoi(e) : 2;   // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
+    }();
+    if (a.n_steps < min_steps || h->kind > RMAV_QUAD3D_SL) return false;
     const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
     if (forced == 0) return false;
     if (h->n <= cap) return true;

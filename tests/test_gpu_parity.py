@@ -176,12 +176,13 @@ def test_lifetime_terminal_reward_once(G, kind, golden):
     env.close()
 
 
+@pytest.mark.parametrize("T", [24, 2, 5, 7])
 @pytest.mark.parametrize("mode", ["random", "controller", "buffer"])
 @pytest.mark.parametrize("kind", KINDS)
-def test_fused_rollout_equals_single_steps(G, kind, mode):
+def test_fused_rollout_equals_single_steps(G, kind, mode, T):
     """The fused kernel (state in registers for T steps) and T launches of the step kernel give the
-    same bits, including auto-resets and episode statistics."""
-    n, T, seed = 5000, 24, 3
+    same bits, including auto-resets and episode statistics - short launches (two-wavefront kernel from 2 steps) too."""
+    n, seed = 5000, 3
     acts = None
     if mode == "buffer":
         rng = np.random.RandomState(4)

@@ -12,7 +12,7 @@ bad = 0
 for it in range(int(os.environ.get("ITERS", "300"))):
     kind = ["quad3d", "quad2d", "quad3d_sl", "quad2d_sl"][it % 4]
     n = int(rng.choice([1, 63, 64, 65, 127, 1000, 10001, 20001, 65536, 70000]))
-    T = int(rng.choice([8, 9, 11, 12, 31, 64, 96]))
+    T = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 12, 31, 64, 96]))
     seed = int(rng.randint(1 << 30))
     mode = ["random", "controller"][(it // 4) % 2]
     res = []
