@@ -273,12 +273,12 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     if constexpr (is_split(MODE)) {
         // (integrator, memory wavefront) pairs: as many per workgroup as make ONE workgroup per CU (256 workgroups),
         // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_SPLIT_GROUP=1..8 overrides.
-        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, MODE == ACT_RANDOM_SPLIT>;
+        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, split_feeds_actions(MODE)>;
         static const int forced = [] {
             const char *e = getenv("RMAV_SPLIT_GROUP");
             return e ? atoi(e) : 0;
         }();
-        constexpr int g_max = split_pairs_max<K, MODE == ACT_RANDOM_SPLIT>();
+        constexpr int g_max = split_pairs_max<K, split_feeds_actions(MODE)>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
         int g = (forced >= 1 && forced <= g_max) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
         if (g < 1) g = 1;
@@ -300,7 +300,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
 // RMAV_SPLIT=0|1 overrides the rule.
 // Batches beyond that capacity can still run on the two-wavefront kernel as a sequence of launches over balanced
 // slices of the env range, each one workgroup per CU (`slices` > 1): see launch_rollout_km.  RMAV_SLICE=0|1 overrides.
-bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
+bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, bool random_actions) {
     static const int forced = [] {
         const char *e = getenv("RMAV_SPLIT");
         return e ? atoi(e) : -1;
@@ -324,7 +324,7 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices) {
     // BASELINE C4 = quadrotor3d-slungload at 262 144 envs 269-292 -> 249-252 us, quadrotor2d-slungload 172 -> 158).  Smaller
     // second halves, more than two rounds, the plain kinds (quadrotor3d: +-4 %, quadrotor2d: slower) and the
     // controller-driven rollouts measured equal or slower, so they stay on one launch.
-    const bool two_rounds = draws && (h->kind == RMAV_QUAD3D_SL || h->kind == RMAV_QUAD2D_SL) && h->n <= 2 * cap &&
+    const bool two_rounds = random_actions && (h->kind == RMAV_QUAD3D_SL || h->kind == RMAV_QUAD2D_SL) && h->n <= 2 * cap &&
                             4 * h->n >= 7 * cap;
     if (slice_forced == 1 || (slice_forced != 0 && (kSliceByDefault || two_rounds))) {
         *slices = (int)((h->n + cap - 1) / cap);
@@ -339,10 +339,10 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
     if constexpr (is_policy(MODE)) {
         return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
     } else {
-        if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER) && K != REINMAV) {
-            constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : ACT_CONTROLLER_SPLIT;
+        if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER || MODE == ACT_BUFFER) && K != REINMAV) {
+            constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : (MODE == ACT_BUFFER) ? ACT_BUFFER_SPLIT : ACT_CONTROLLER_SPLIT;
             int slices = 1;
-            if (use_split(h, a, MODE == ACT_RANDOM, &slices)) {
+            if (use_split(h, a, MODE != ACT_CONTROLLER, &slices, MODE == ACT_RANDOM)) {
                 const int st = pick_store_policy(h, a, true);
                 // balanced slices, each a multiple of 64 envs
                 const int64_t per = slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;

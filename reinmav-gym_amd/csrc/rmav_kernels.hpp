@@ -38,10 +38,14 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
               // (rmav_step_control: the gym-shaped single env gets step()'s outputs and the NEXT control() in one launch)
               ACT_BUFFER_CTRL = 7,
               // the fp32 policy on the fp32-input matrix instructions (rmav_policy_mfma32.hpp)
-              ACT_POLICY_F32M = 8 };
+              ACT_POLICY_F32M = 8,
+              // internal: ACT_BUFFER with the memory wavefront prefetching the caller's actions into the hand-over tile
+              ACT_BUFFER_SPLIT = 9 };
 constexpr bool is_mfma_policy(int mode) { return mode == ACT_POLICY_BF16 || mode == ACT_POLICY_F32M; }
 constexpr bool is_policy(int mode) { return mode == ACT_POLICY || is_mfma_policy(mode); }
-constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT; }
+constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT || mode == ACT_BUFFER_SPLIT; }
+// split modes whose memory wavefront hands actions TO the integrator (drawn, or fetched from the caller's buffer)
+constexpr bool split_feeds_actions(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_BUFFER_SPLIT; }
 constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
 // Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
 // (actions: helper -> integrator, only when the helper draws them; obs + reward + done [+ actions]: integrator -> helper)
@@ -73,7 +77,7 @@ template <int K, bool DRAWS> constexpr int split_group_cap() {
 #endif
 constexpr int kBlock = RMAV_KBLOCK;  // upper bound (launch bounds); the launch may use 64/128/256 (.. RMAV_KBLOCK)
 template <int K, int MODE> constexpr int rollout_threads_max() {   // launch bounds of k_rollout<K, MODE, *>
-    return is_split(MODE) ? 128 * split_group_cap<K, MODE == ACT_RANDOM_SPLIT>() : kBlock;
+    return is_split(MODE) ? 128 * split_group_cap<K, split_feeds_actions(MODE)>() : kBlock;
 }
 template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int CH = kSplitChunk;   // env-steps per hand-over
@@ -203,6 +207,9 @@ __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t sof
 // interleaved repetitions): random-action rollouts 0-8 % slower, controller-driven ones 0-4 % faster; and the memory
 // system absorbs 16-byte and 4-byte stores at the same rate (tools/micro/store_patterns.hip).  -DRMAV_WIDE_DRAIN=1
 // builds it; both drains pass the parity suite bit for bit.
+#ifndef RMAV_BUF_PREFETCH
+#define RMAV_BUF_PREFETCH 4   // hand-overs the memory wavefront fetches the caller's actions ahead (ACT_BUFFER_SPLIT)
+#endif
 #ifndef RMAV_WIDE_DRAIN
 #define RMAV_WIDE_DRAIN 0
 #endif
@@ -236,7 +243,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;
     // ACT_RANDOM_SPLIT: 128-thread workgroups, both wavefronts address the same 64 envs
-    constexpr bool SPLIT = is_split(MODE), DRAWS = (MODE == ACT_RANDOM_SPLIT);
+    constexpr bool SPLIT = is_split(MODE), DRAWS = split_feeds_actions(MODE);   // DRAWS: the hand-over has an action tile
     [[maybe_unused]] constexpr int CH = SplitTile<NS, NA, DRAWS>::CH;   // env-steps per hand-over (split modes)
     // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
     const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
@@ -440,12 +447,56 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                     }
                 }
             };
-            if constexpr (DRAWS) fill(0);
-            __syncthreads();                                   // B0
-            for (int32_t c = 1; c < nc; ++c) {
-                if constexpr (DRAWS) fill(c);
-                if (c >= 2) drain(c - 2);
-                __syncthreads();                               // Bc
+            if constexpr (MODE == ACT_BUFFER_SPLIT) {
+                // The caller's actions come from HBM: fetched D hand-overs ahead into registers (a load issued one hand-over
+                // ahead exposed its ~1 us round trip on every env-step: 71 us per 64-step launch at 65 536 envs instead of 41).
+                static_assert(CH == 1, "one env-step per hand-over");
+                constexpr int D = RMAV_BUF_PREFETCH;
+                float pre[D][NA];
+                auto issue = [&](int32_t k, float (&dst)[NA]) {
+                    if (k < T) {
+                        const float *src_step = a.act_in + (int64_t)k * NA * n;
+                        if (aos) {
+                            const float *src = src_step + (int64_t)li * NA;
+#pragma unroll
+                            for (int q = 0; q < NA; ++q) dst[q] = src[q];
+                        } else {
+                            const rsrc_t ri = make_rsrc(src_step);
+#pragma unroll
+                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(ri, off, (uint32_t)q * col);
+                        }
+                    }
+                };
+                auto put = [&](int32_t c, const float (&src)[NA]) {
+                    float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
+#pragma unroll
+                    for (int q = 0; q < NA; ++q) buf[q * 64] = src[q];
+                };
+#pragma unroll
+                for (int d = 0; d < D; ++d) issue(d, pre[d]);
+                put(0, pre[0]);
+                issue(D, pre[0]);
+                __syncthreads();                               // B0
+                for (int32_t cb = 1; cb < nc; cb += D) {
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {              // step c = cb + d lives in slot (1 + d) % D: static register indices
+                        const int32_t c = cb + d;
+                        if (c < nc) {                          // wave- and workgroup-uniform
+                            put(c, pre[(1 + d) % D]);
+                            issue(c + D, pre[(1 + d) % D]);
+                            if (c >= 2) drain(c - 2);
+                            __syncthreads();                   // Bc
+                        }
+                    }
+                }
+            } else {
+                if constexpr (DRAWS) fill(0);
+                __syncthreads();                                   // B0
+                for (int32_t c = 1; c < nc; ++c) {
+                    if constexpr (DRAWS) fill(c);
+                    if (c >= 2) drain(c - 2);
+                    __syncthreads();                               // Bc
+                }
             }
             if (nc >= 2) drain(nc - 2);
             __syncthreads();                                   // B(nc)
@@ -627,7 +678,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 if (k + 1 < a.n_steps) load_actions(act_in, act_pre);
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
-            } else if constexpr (MODE == ACT_RANDOM_SPLIT) {
+            } else if constexpr (split_feeds_actions(MODE)) {
                 if ((k % CH) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
                 const float *buf = lds_p + ((k / CH) & 1) * SplitTile<NS, NA, true>::A_HALF +
                                    (k % CH) * (NA * 64) + (threadIdx.x & 63u);
