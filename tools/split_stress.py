@@ -14,11 +14,16 @@ for it in range(int(os.environ.get("ITERS", "300"))):
     n = int(rng.choice([1, 63, 64, 65, 127, 1000, 10001, 20001, 65536, 70000]))
     T = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 11, 12, 31, 64, 96]))
     seed = int(rng.randint(1 << 30))
-    mode = ["random", "controller"][(it // 4) % 2]
+    mode = ["random", "controller", "buffer"][(it // 4) % 3]
+    layout = ["soa", "aos"][(it // 12) % 2]
+    acts = None
+    if mode == "buffer":   # caller-provided actions ([T][nA][N] or [T][N][nA])
+        nA = 4 if kind.startswith("quad3d") else 2
+        acts = torch.empty((T, nA, n) if layout == "soa" else (T, n, nA), device="cuda").uniform_(0, 10, generator=torch.Generator(device="cuda").manual_seed(seed))
     res = []
     for fused in (True, False):
         env = g.BatchedQuadrotor(kind, n, seed=seed, auto_reset=True, track_episodes=True)
-        tr = env.rollout(T, mode=mode, layout=["soa", "aos"][(it // 8) % 2], fused=fused, want=("actions", "obs", "rew", "done"), device_out=True)
+        tr = env.rollout(T, mode=mode, actions=acts, layout=layout, fused=fused, want=("actions", "obs", "rew", "done"), device_out=True)
         res.append((tr, env.get_state(layout="soa", device_out=True), env.episode_totals(), env.episode_buffers(device_out=True)))
         env.close()
     (a, sa, ta, ea), (b, sb, tb, eb) = res
