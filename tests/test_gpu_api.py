@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from util import CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, scaled_err
+from util import BOX, CTRL_TOL, KINDS, NA, NS, TOL, near_threshold, scaled_err
 
 pytestmark = pytest.mark.gpu
 
@@ -330,3 +330,25 @@ def test_largest_supported_batch_and_limit(G):
     assert np.array_equal(one.get_state(layout="soa")[:, 0], s[:, -1])
     env.close()
     one.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_fused_rollout_with_host_action_arrays_small_batches(G, kind):
+    """Caller-provided actions as NumPy arrays: batches small enough for the pinned zero-copy path (the two-wavefront kernel
+    then reads them over PCIe, four hand-overs ahead) and bigger ones (staged): same bits as single steps, both layouts."""
+    rng = np.random.RandomState(2)
+    for n in (1, 7, 64, 100, 3000):
+        for T in (2, 3, 9, 24):
+            for layout in ("soa", "aos"):
+                acts = rng.uniform(*BOX[kind], (T, NA[kind], n) if layout == "soa" else (T, n, NA[kind])).astype(np.float32)
+                res = []
+                for fused in (True, False):
+                    env = G.BatchedQuadrotor(kind, n, seed=3)
+                    tr = env.rollout(T, mode="buffer", actions=acts, layout=layout, fused=fused, want=("obs", "rew", "done"))
+                    res.append((tr, env.get_state(), env.episode_totals(), env.get_reset_counts()))
+                    env.close()
+                (a, sa, ta, ca), (b, sb, tb, cb) = res
+                for k in a:
+                    assert np.array_equal(a[k], b[k]), (kind, n, T, layout, k)
+                assert np.array_equal(sa, sb) and np.array_equal(ca, cb) and ta["episodes"] == tb["episodes"]
+
