@@ -162,8 +162,9 @@ def main():
                     help="timed launches (SURVEY 8d asks for >= 1000 after >= 100 warm-up; 2000 launches ~ 0.1-0.2 s)")
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--kind", default="quad3d", choices=["quad2d", "quad2d_sl", "quad3d", "quad3d_sl", "reinmav"])
-    ap.add_argument("--actions", default="random", choices=["random", "controller"],
-                    help="action source of the fused rollout (controller = the reference's built-in / geometric controller)")
+    ap.add_argument("--actions", default="random", choices=["random", "controller", "buffer"],
+                    help="action source of the fused rollout (controller = the reference's built-in / geometric controller; "
+                         "buffer = caller-provided actions, read from a ring of [chunk][nA][N] device buffers)")
     ap.add_argument("--envs-per-gpu", type=int, default=None,
                     help="default: 65536 on one GPU (BASELINE C2), 131072 per GPU on several (C3's shard)")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
@@ -283,6 +284,9 @@ def main():
                     "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev),
                 } for _ in range(R)]
                 it = [0]
+                if args.actions == "buffer":   # the ring's action buffers are the INPUT: filled once, read every launch
+                    for b in ring:
+                        b["actions"].uniform_(lo, hi)
 
                 arm = exchange is not None and not gloo and os.environ.get("RMAV_BENCH_ARM", "1") == "1"
 
@@ -290,8 +294,13 @@ def main():
                     for _ in range(k):
                         if arm and (it[0] + 1) % args.exchange_every == 0:   # this launch writes the exchange's snapshot itself
                             exchange.arm(env)
-                        env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
-                                    want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
+                        if args.actions == "buffer":
+                            b = ring[it[0] % R]
+                            env.rollout(chunk, mode="buffer", actions=b["actions"], layout=args.layout, fused=True,
+                                        want=("obs", "rew", "done"), device_out=True, out={k: b[k] for k in ("obs", "rew", "done")})
+                        else:
+                            env.rollout(chunk, mode=args.actions, layout=args.layout, fused=True,
+                                        want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
                         it[0] += 1
                         if exchange is not None and it[0] % args.exchange_every == 0:   # the path's one exchange, once per rollout
                             if gloo:
@@ -461,7 +470,7 @@ def main():
             "config": {
                 "workload": (f"{cfg_name}: {ENV_ID[kind]}, {n} envs per GPU ({n_total} total, global env ids {rank * n}.. per rank), "
                              f"random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
-                             + (f"one step = one fused rollout launch = {per_launch} env-steps per env, in-kernel action source '{args.actions}', "
+                             + (f"one step = one fused rollout launch = {per_launch} env-steps per env, action source '{args.actions}', "
                                 f"trajectory (actions, obs, reward, done) written to HBM into "
                                 + ("ONE buffer set rewritten in place" if R == 1 else f"a ring of {R} buffer sets ({R * traj_bytes(per_launch) / 1e9:.2f} GB: cold stores)")
                                 if args.mode == "rollout"
