@@ -155,6 +155,80 @@ def fused_bytes_per_launch(n: int, chunk: int, nS: int, nA: int) -> int:
     return n * (chunk * (4 * (nS + nA + 1) + 1) + 8 * nS + 24)
 
 
+def lookup_traffic(key: str):
+    """HBM-side bytes per launch of this exact workload from the round's rocprofv3 --pmc passes (profiles/traffic.json, written
+    by tools/parse_rocprof.py from separate FETCH_SIZE / WRITE_SIZE runs of the same command line; counters cannot be
+    collected inside this process).  -> (bytes | None, source | None); a source whose file is not in the repo is dropped."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        ent = json.load(open(tpath)).get(key)
+        if ent:
+            src = ent.get("source") or ""
+            if not os.path.exists(os.path.join(ROOT, src.split(" ")[0])):
+                src = "profiles/traffic.json (summary file not in the repo)"
+            return float(ent["bytes"]), src
+    except Exception:
+        pass
+    return None, None
+
+
+def roofline_obj(bytes_launch: float, launch_ms: float, traffic, traffic_src, definition: str, extra=None):
+    achieved = bytes_launch / (launch_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": traffic, "traffic_source": traffic_src,
+         "traffic_over_needed": (traffic / bytes_launch) if traffic else None,
+         "bytes_per_launch": bytes_launch, "bytes_definition": definition, "launch_ms_hip_events": launch_ms}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, label: str, tune=None):
+    """One more single-GPU BASELINE config as its own short measurement: fused random-action rollouts of `kind` over `n` envs
+    into a cold ring of trajectory buffer sets, timed with HIP events on the launch stream (same method as the headline)."""
+    A = g._abi
+    K_ = A.KIND_BY_NAME[kind]
+    nS, nA = A.STATE_DIM[K_], A.ACTION_DIM[K_]
+    per_set = n * chunk * (4 * (nS + nA + 1) + 1)
+    R = max(5, -(-int(1.5e9) // per_set))
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        if tune:
+            env.set_tuning(**tune)
+        ring = [{"actions": torch.zeros((chunk, nA, n), dtype=torch.float32, device=dev),
+                 "obs": torch.zeros((chunk, nS, n), dtype=torch.float32, device=dev),
+                 "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
+                 "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev)} for _ in range(R)]
+        it = 0
+        for phase, count in (("warm", W), ("timed", K)):
+            if phase == "timed":
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(stream)
+            for _ in range(count):
+                env.rollout(chunk, mode="random", layout="soa", fused=True, want=("actions", "obs", "rew", "done"),
+                            device_out=True, out=ring[it % R])
+                it += 1
+        e1.record(stream)
+        stream.synchronize()
+        wall = time.perf_counter() - t0
+        ms = e0.elapsed_time(e1) / K
+        fin = env.episode_totals()["episodes"]
+        env.close()
+    del ring
+    torch.cuda.empty_cache()
+    b = fused_bytes_per_launch(n, chunk, nS, nA)
+    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa")
+    return {"workload": f"{label}: {ENV_ID[kind]}, {n} envs, random actions, auto-reset, episode tracking; {chunk}-step fused launches "
+                        f"into a ring of {R} trajectory buffer sets ({R * per_set / 1e9:.2f} GB: cold stores)",
+            "launches": K, "warmup": W, "value": n * chunk * K / wall, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * wall / K,
+            "finished_episodes": fin,
+            "roofline": roofline_obj(b, ms, tr, src, f"{n} envs x ({chunk} env-steps x {4 * (nS + nA + 1) + 1} B trajectory out + "
+                                                     f"{8 * nS + 24} B state / episode bookkeeping per launch)")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +255,9 @@ def main():
     ap.add_argument("--action-ring", type=int, default=64, help="step mode: number of pre-generated action buffers")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
-    ap.add_argument("--secondary", default="in_place,step,gym1,vecenv,policy",
+    ap.add_argument("--tune", default="", help="comma list of key=value overrides of the launch heuristics (rmav_set_tuning), "
+                                               "e.g. split=0,store_policy=2")
+    ap.add_argument("--secondary", default="in_place,step,c3_shard,c4,gym1,vecenv,policy",
                     help="comma list of the other measurements to add under other_modes (single process only)")
     args = ap.parse_args()
 
@@ -228,6 +304,9 @@ def main():
     with torch.cuda.stream(stream):
         env = g.BatchedQuadrotor(kind, n, device=local_dev, seed=0, env_id_base=rank * n, auto_reset=True,
                                  track_episodes=True)
+        tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv}
+        if tune:
+            env.set_tuning(**tune)
         gloo = use_dist and dist.get_backend() == "gloo"
         exchange, exchange_kind, native_abandoned = None, None, False
         if use_dist:
@@ -325,6 +404,8 @@ def main():
                     k -= m
             return run, 1, 1
 
+        prewarm_launches = [0]
+
         def measure(mode, chunk, K, W, in_place=False, prewarm_ms=0.0):
             run, per_launch, R = make_runner(mode, chunk, in_place)
             if prewarm_ms > 0:
@@ -334,7 +415,8 @@ def main():
                 # (a launch COUNT derived from the problem size, not a wall-clock loop: every rank must issue the same
                 # number of launches - each one posts a collective)
                 est_us = (0.72 * per_launch if mode == "rollout" else 5.0) * max(1.0, n / 65536.0)
-                run(max(1, int(prewarm_ms * 1e3 / est_us)))
+                prewarm_launches[0] = max(1, int(prewarm_ms * 1e3 / est_us))
+                run(prewarm_launches[0])
                 stream.synchronize()
             run(W)
             stream.synchronize()
@@ -366,10 +448,18 @@ def main():
         if "step" in sec or "in_place" in sec:
             if args.mode == "rollout" and "step" in sec:
                 w2, k2, pl2, _, _ = measure("step", 1, 4000, 200)
-                other["step"] = {"launches": 4000, "env_steps_per_launch": n, "value": n * 4000 / w2, "unit": "env-steps/s",
-                                 "ms_per_launch_wall": 1e3 * w2 / 4000, "ms_per_launch_hip_events": k2,
-                                 "bytes_per_env_step": algo_bytes,
-                                 "roofline_frac": algo_bytes * n / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                tr2, src2 = lookup_traffic(f"{kind}:step:1:{n}:inplace:{args.actions}:soa")
+                other["step"] = {"workload": "one launch of k_step per env-step (rmav_step's kernel; the loop runs inside rmav_rollout(fused = 0)): "
+                                             "actions read from a ring of 64 device buffers, state updated in place, reward + done written, "
+                                             "auto-reset + episode tracking on",
+                                 "launches": 4000, "env_steps_per_launch": n, "value": n * 4000 / w2, "unit": "env-steps/s",
+                                 "ms_per_launch_wall": 1e3 * w2 / 4000,
+                                 "roofline": roofline_obj(algo_bytes * n, k2, tr2, src2,
+                                                          f"{n} envs x {algo_bytes} B (SURVEY 8d: state in/out, action in, reward + done out); the "
+                                                          "episode bookkeeping the VecEnv contract adds (running return in/out, steps_beyond_done and "
+                                                          "reset counter in: 16 B per env-step) is traffic beyond this definition",
+                                                          {"launch_floor_note": "an EMPTY 65 536-thread kernel chain runs 2.8-2.9 us per launch on this "
+                                                                                "GPU (tools/micro/launch_floor.hip), i.e. frac <= 0.29 for any one-launch-per-step kernel"})}
             if args.mode == "rollout" and "in_place" in sec and not args.in_place:
                 w2, k2, pl2, _, _ = measure("rollout", args.chunk, 500, 100, in_place=True)
                 b2 = fused_bytes_per_launch(n, args.chunk, nS, nA)
@@ -378,6 +468,14 @@ def main():
                             "256 MiB Infinity Cache, so the stores are cache-assisted (round 1's headline)",
                     "launches": 500, "value": n * pl2 * 500 / w2, "unit": "env-steps/s", "ms_per_launch_hip_events": k2,
                     "roofline_frac": b2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if single and kind == "quad3d" and args.mode == "rollout":
+            try:   # the other single-GPU BASELINE configs, each a short leg with its own roofline object
+                if "c3_shard" in sec and n != 131072:
+                    other["c3_shard"] = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 600, 150, "BASELINE configs[2]'s per-GPU shard")
+                if "c4" in sec:
+                    other["c4"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80, "BASELINE configs[3] (C4)")
+            except Exception as e:  # pragma: no cover
+                other["legs_error"] = repr(e)
         # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
         # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
         with DeviceSampler(dev.index or 0) as sampler:
@@ -439,15 +537,7 @@ def main():
         bytes_def = f"{n} envs x {algo_bytes} B (SURVEY 8d: state in/out, action in, reward + done out)"
     achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9  # GB/s, one GPU's dominant kernel
     tkey = f"{kind}:{args.mode}:{per_launch}:{n}:{'inplace' if (args.in_place or args.mode == 'step') else 'ring'}:{args.actions}:{args.layout}"
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")  # rocprofv3 --pmc bytes per launch of this very command line
-    if os.path.exists(tpath):
-        try:
-            ent = json.load(open(tpath)).get(tkey)
-            if ent:
-                traffic, traffic_src = float(ent["bytes"]), ent.get("source")
-        except Exception:
-            traffic = None
+    traffic, traffic_src = lookup_traffic(tkey)   # rocprofv3 --pmc bytes per launch of this very command line
 
     if rank == 0:
         cfg_name = ("BASELINE configs[1] (C2)" if (world == 1 and n == 65536 and kind == "quad3d") else
@@ -461,6 +551,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_ms": args.prewarm_ms,            # untimed stretch of the same launches AHEAD of the warm-up (GPU clock ramp) ...
+            "prewarm_launches": prewarm_launches[0],  # ... and the number of launches it was
             "ms_per_step": 1e3 * wall / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
@@ -501,6 +593,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "traffic_over_needed": (traffic / bytes_launch) if traffic else None,
                 "bytes_per_launch": bytes_launch,
                 "bytes_definition": bytes_def,
                 "launch_ms_hip_events": kernel_ms,
@@ -657,8 +750,40 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
         e2.record()
         torch.cuda.synchronize()
         ms_ro, ms_gae = e0.elapsed_time(e1) / iters, e1.elapsed_time(e2) / iters
-        out[actor] = {"ms_per_rollout_incl_weight_pack": ms_ro, "env_steps_per_s": n * T / (ms_ro * 1e-3),
-                                                "gae_ms": ms_gae, "gae_GBps": 17.0 * n * T / (ms_gae * 1e-3) / 1e9}
+        # the rollout kernel alone (weights already packed): what its two rooflines are priced on
+        e3, e4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        C_, A_ = ro._C, ro._A
+        pp = lambda t: C_.c_void_p(t.data_ptr())  # noqa: E731
+        prec = A_.POLICY_BF16_MFMA if actor == "bf16_mfma" else A_.POLICY_FP32_MFMA if actor == "fp32_mfma" else A_.POLICY_FP32
+        e3.record()
+        for _ in range(iters):
+            A_.check(A_.lib().rmav_rollout_policy(env._h, T, pp(ro.weights), pp(ro.act), pp(ro.obs[1:]), pp(ro.rew), pp(ro.done),
+                                                  pp(ro.logp), pp(ro.val), prec))
+        e4.record()
+        torch.cuda.synchronize()
+        ms_k = e3.elapsed_time(e4) / iters
+        nS, nA = env.nS, env.nA
+        hbm_b = n * (T * (4 * (nS + nA + 1) + 1 + 8) + 8 * nS + 24 + 4)   # trajectory + logp + value per step; state etc. per launch
+        useful = 2 * ((nS * 64 + 64 * 64 + 64 * nA) + (nS * 64 + 64 * 64 + 64))          # policy net + value net, per env-step
+        roof = {"hbm": roofline_obj(hbm_b, ms_k, None, None,
+                                    f"{n} envs x ({T} env-steps x {4 * (nS + nA + 1) + 1 + 8} B (actions, obs, reward, done, logp, value) + "
+                                    f"{8 * nS + 28} B per launch)")}
+        if actor != "fp32_valu":
+            # matrix-pipe work incl. tile padding: bf16 = 56 v_mfma_f32_32x32x16_bf16 per 64 envs and step (inputs padded 10 -> 16,
+            # outputs 4 / 1 -> 32); fp32 = 2 nets x (2 ceil(nS / 2) + 64) v_mfma_f32_32x32x2_f32 per 32 envs (layer 3 on the vector ALU)
+            padded = 56 * 2 * 32 * 32 * 16 / 64 if actor == "bf16_mfma" else 2 * (2 * ((nS + 1) // 2) + 64) * 2 * 32 * 32 * 2 / 32
+            peak = 2500.0 if actor == "bf16_mfma" else 157.3   # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+            ach = padded * n * T / (ms_k * 1e-3) / 1e12
+            roof["mfma"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                            "flops_per_env_step_incl_tile_padding": padded, "useful_flops_per_env_step": useful,
+                            "useful_frac": useful * n * T / (ms_k * 1e-3) / 1e12 / peak}
+        else:
+            ach = useful * n * T / (ms_k * 1e-3) / 1e12
+            roof["valu"] = {"bound": "valu_fp32", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
+                            "useful_flops_per_env_step": useful}
+        out[actor] = {"ms_per_rollout_incl_weight_pack": ms_ro, "ms_per_rollout_kernel": ms_k,
+                      "env_steps_per_s": n * T / (ms_ro * 1e-3), "kernel_env_steps_per_s": n * T / (ms_k * 1e-3),
+                      "gae_ms": ms_gae, "gae_GBps": 17.0 * n * T / (ms_gae * 1e-3) / 1e9, "roofline": roof}
         env.close()
     return out
 

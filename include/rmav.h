@@ -99,7 +99,8 @@ enum rmav_status {
     RMAV_ERR_INVALID = -1,   /* bad argument */
     RMAV_ERR_NO_DEVICE = -2, /* no usable GPU */
     RMAV_ERR_HIP = -3,       /* a HIP runtime call failed (message has the HIP error string) */
-    RMAV_ERR_ALLOC = -4      /* device / host allocation failed */
+    RMAV_ERR_ALLOC = -4,     /* device / host allocation failed */
+    RMAV_ERR_TIMEOUT = -5    /* a bounded wait expired (rmav_allgather_stats_wait, an armed exchange whose launch never completed) */
 };
 
 enum rmav_mem { RMAV_HOST = 0, RMAV_DEVICE = 1 };
@@ -185,6 +186,21 @@ int rmav_set_stream(rmav_handle h, void *hip_stream);
  * or NULL to go back to the shared value of rmav_params.  Quadrotor kinds only. */
 enum rmav_env_param { RMAV_PARAM_MASS = 0, RMAV_PARAM_LOAD_MASS = 1, RMAV_PARAM_TETHER_LENGTH = 2 };
 int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem);
+/* Explicit, per-handle overrides of the launch heuristics (DESIGN.md section 4 states the automatic rules and the
+ * measurements behind them).  -1 = automatic (the default for every key).  Results never depend on these: every
+ * variant produces the same bits (tests/test_gpu_parity.py::test_rollout_bits_do_not_depend_on_kernel_variant). */
+enum rmav_tuning_key {
+    RMAV_TUNE_SPLIT = 0,           /* fused rollouts: 0 = one wavefront per 64 envs, 1 = integrator + memory wavefront pairs */
+    RMAV_TUNE_SLICE = 1,           /* batches beyond the two-wavefront capacity: 0 = one launch, 1 = one launch per slice */
+    RMAV_TUNE_STORE_POLICY = 2,    /* trajectory stores: 0 write-back, 1 write-through, 2 non-temporal, 3 LDS-transposed AoS */
+    RMAV_TUNE_SPLIT_GROUP = 3,     /* (integrator, memory wavefront) pairs per workgroup, 1 .. 8 */
+    RMAV_TUNE_BLOCK = 4,           /* workgroup size of the one-wavefront kernels: 64 | 128 | 256 */
+    RMAV_TUNE_STEP_KERNEL = 5,     /* 0: single-step calls use the rollout kernel at n_steps = 1 instead of k_step */
+    RMAV_TUNE_SPLIT_MIN_STEPS = 6, /* shortest fused launch that may use the two-wavefront kernel (default 2) */
+    RMAV_TUNE_COUNT = 7
+};
+int rmav_set_tuning(rmav_handle h, int key, int value);
+int rmav_get_tuning(rmav_handle h, int key, int *value_out);
 int64_t rmav_num_envs(rmav_handle h); /* < 0 on a bad handle */
 int rmav_sync(rmav_handle h);         /* waits for everything enqueued on the handle's stream */
 
@@ -300,10 +316,18 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
  * rmav_rollout_policy launch of `h` then writes the snapshot itself (every wavefront stores its envs' statistics into
  * the exchange's send buffer and publishes an arrival word; the communicator's stream polls those), so that _post puts
  * NOTHING into the handle's stream - no pack kernel, no signal kernel (~8 us per post at 131 072 envs).  Same snapshot,
- * same result.  If no such launch happens between _arm and _post (single-step launches, a sliced launch), _post packs
- * as usual.  One armed exchange per handle at a time; _post with the same communicator consumes it. */
+ * same result.  Only a call that is ONE fused launch over all of the handle's envs takes the snapshot; if none happens
+ * between _arm and _post (single-step launches incl. rmav_rollout(fused = 0), a sliced launch), or if another stepping
+ * launch follows the one that took it, _post packs as usual.  The communicator stream's wait for the armed launch is
+ * bounded (2 s): past that, _post / _result / _wait return RMAV_ERR_TIMEOUT.  One armed exchange per handle at a time;
+ * _post with the same communicator consumes it; destroying the communicator disarms the handle. */
 int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total);
 int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
+/* HOST-side bounded wait for the most recently posted exchange (polls its completion event; touches no stream):
+ * RMAV_OK once the gather has finished, RMAV_ERR_TIMEOUT after timeout_s seconds (< 0: no limit).  Lets a caller probe a
+ * freshly created communicator - post, wait with a deadline, only then _result - without ever parking a handle's stream
+ * behind a collective that may never complete. */
+int rmav_allgather_stats_wait(rmav_comm c, double timeout_s);
 /* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
  * send_out i32 [2][cmax] (DEVICE) <- bit patterns of the per-env last returns, then the last lengths, zero padded
  * from num_envs to cmax (the largest shard).  A stream-ordered snapshot in one small launch, so the next

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 
 #include <dlfcn.h>
@@ -83,14 +84,19 @@ struct rmav_env_s {
     // snapshot their envs' statistics and publish their arrival; `fired` once a launch has taken it
     struct {
         bool armed, fired;
+        bool allow;   // the call in progress is ONE fused launch over all envs (set by rollout_impl / rmav_rollout_policy)
+        bool stale;   // another stepping launch followed the one that took the snapshot: _post must pack again
         struct rmav_comm_s *comm;
         int slot;
         int64_t cmax;
         uint32_t seq, expected;
     } xchg;
+    // explicit per-handle overrides of the launch heuristics (rmav_set_tuning); -1 / 0 = automatic
+    int tune[RMAV_TUNE_COUNT];
 };
 
 constexpr int kExchangeDepth = 8;   // buffer pairs of the overlapped statistics exchange
+constexpr unsigned long long kArrivalWaitTicks = 200000000ull;   // 2 s of the 100 MHz wall clock: bound of k_wait_arrivals
 struct rmav_comm_s {
     uint32_t magic;
     int rank, world, device;
@@ -105,6 +111,9 @@ struct rmav_comm_s {
     uint32_t *flag;    // signal word (hipMallocSignalMemory): the compute stream publishes post numbers, the comm stream waits
     int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
     int posts;         // number of posts so far (buffer pair of post i is i % depth)
+    struct rmav_env_s *armed_by;   // the handle whose armed exchange points at this communicator (cleared by _post)
+    uint32_t *timeout_flag;        // pinned host word (device-mapped): k_wait_arrivals sets it when it gives up
+    uint32_t *timeout_flag_dev;
 };
 
 namespace {
@@ -140,17 +149,12 @@ int check_params(const rmav_params &q) {
 // slots of the per-wavefront episode totals: one per 32 envs (the fp32-MFMA policy mode runs 32 envs per wavefront)
 inline size_t n_total_slots(int64_t n) { return (size_t)((n + 31) / 32); }
 
-// Workgroup size: 256 by default; RMAV_BLOCK=64|128|256 overrides it (tuning knob, read once).
-
-int block_size() {
-    static int b = [] {
-        const char *e = getenv("RMAV_BLOCK");
-        int v = e ? atoi(e) : 256;
-        return (v == 64 || v == 128 || v == 256 || ((v == 512 || v == 1024) && v <= kBlock)) ? v : (kBlock > 256 ? 256 : kBlock);
-    }();
-    return b;
+// Workgroup size of the one-wavefront-per-64-envs kernels: 256, or rmav_set_tuning(RMAV_TUNE_BLOCK, 64 | 128 | 256).
+inline int block_size(rmav_handle h) {
+    const int v = h->tune[RMAV_TUNE_BLOCK];
+    return (v == 64 || v == 128 || v == 256) ? v : 256;
 }
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + block_size() - 1) / block_size())); }
+inline dim3 grid_for(rmav_handle h) { return dim3((unsigned)((h->n + block_size(h) - 1) / block_size(h))); }
 
 int ensure_scratch(rmav_handle h, size_t bytes) {
     if (bytes <= h->scratch_bytes) return RMAV_OK;
@@ -203,12 +207,9 @@ int ensure_pinned(rmav_handle h, size_t bytes) {
 //   one-wavefront kernel : non-temporal (nt) is best from 131 072 envs up (+3..7 % over the default policy, which is
 //                          never the best choice for a fused launch); small trajectories that stay in the Infinity
 //                          Cache for their consumer keep write-through
-// Single-step and very short launches use the default policy.  RMAV_STORE_POLICY=0|1|2 overrides.
+// Single-step and very short launches use the default policy.  rmav_set_tuning(RMAV_TUNE_STORE_POLICY, 0|1|2|3) overrides.
 int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
-    static const int forced = [] {
-        const char *e = getenv("RMAV_STORE_POLICY");
-        return e ? atoi(e) : -1;
-    }();
+    const int forced = h->tune[RMAV_TUNE_STORE_POLICY];
     if (forced >= 0 && forced <= 2 && !(a.flags & F_AOS)) return forced;
     if (a.n_steps < 8 && !split) return ST_DEFAULT;
     double per_step = 0.0;
@@ -217,7 +218,7 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
     if (a.rew_out) per_step += 4.0;
     if (a.done_out) per_step += 1.0;
     const double bytes = per_step * (double)h->n * (double)a.n_steps;
-    if (a.flags & F_AOS) {   // batch-major trajectories: LDS-transposed obs stores once the launch is big (RMAV_STORE_POLICY=3: always, 0: never)
+    if (a.flags & F_AOS) {   // batch-major trajectories: LDS-transposed obs stores once the launch is big (RMAV_TUNE_STORE_POLICY 3: always, 0: never)
         if (forced == 0) return ST_DEFAULT;
         if (split) return ST_WRITE_THROUGH;   // the memory wavefront drains batch-major tiles itself
         // measured (profiles/r01/layout_sweep.md): pays from 131 072 envs x 64 steps (512 MB), costs 10-15 % at 65 536 (256 MB)
@@ -253,8 +254,12 @@ constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches bey
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     RolloutArgs a = a_in;
-    // an armed statistics exchange rides on the first single-launch fused rollout after rmav_allgather_stats_arm
-    if (h->xchg.armed && !h->xchg.fired && a.slice_count == 0 && (a.flags & F_TRACK)) {
+    // An armed statistics exchange rides on the first call after rmav_allgather_stats_arm that is ONE fused launch over all
+    // envs (xchg.allow: rollout_impl with fused != 0 / rmav_rollout_policy; not the fused = 0 loop of single-step launches,
+    // whose first launch would snapshot the statistics T - 1 steps early, and not a sliced launch).  Any later stepping
+    // launch makes that snapshot stale, and _post then packs afresh.
+    if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;
+    if (h->xchg.armed && !h->xchg.fired && h->xchg.allow && a.slice_count == 0 && (a.flags & F_TRACK)) {
         rmav_comm_s *c = h->xchg.comm;
         a.xsend = c->send[h->xchg.slot];
         a.xcmax = h->xchg.cmax;
@@ -268,16 +273,13 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
                        : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
                        : (MODE == ACT_POLICY_F32M) ? sizeof(float) * Mfma32Layout::TOTAL
-                       : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size() / 64)
+                       : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size(h) / 64)
                                                    : 0;
     if constexpr (is_split(MODE)) {
         // (integrator, memory wavefront) pairs: as many per workgroup as make ONE workgroup per CU (256 workgroups),
-        // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_SPLIT_GROUP=1..8 overrides.
+        // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_TUNE_SPLIT_GROUP = 1..8 overrides.
         using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, split_feeds_actions(MODE)>;
-        static const int forced = [] {
-            const char *e = getenv("RMAV_SPLIT_GROUP");
-            return e ? atoi(e) : 0;
-        }();
+        const int forced = h->tune[RMAV_TUNE_SPLIT_GROUP];
         constexpr int g_max = split_pairs_max<K, split_feeds_actions(MODE)>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
         int g = (forced >= 1 && forced <= g_max) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
@@ -287,33 +289,24 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
                            sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
     } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
-        const int64_t per_wg = block_size() / 2;
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size()), lds,
+        const int64_t per_wg = block_size(h) / 2;
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds,
                            h->stream, a, p, pc);
     } else {
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h->n), dim3(block_size()), lds, h->stream, a, p, pc);
+        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h), dim3(block_size(h)), lds, h->stream, a, p, pc);
     }
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
 
-// RMAV_SPLIT=0|1 overrides the rule.
+// RMAV_TUNE_SPLIT = 0 | 1 overrides the rule.
 // Batches beyond that capacity can still run on the two-wavefront kernel as a sequence of launches over balanced
-// slices of the env range, each one workgroup per CU (`slices` > 1): see launch_rollout_km.  RMAV_SLICE=0|1 overrides.
+// slices of the env range, each one workgroup per CU (`slices` > 1): see launch_rollout_km.  RMAV_TUNE_SLICE = 0 | 1 overrides.
 bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, bool random_actions) {
-    static const int forced = [] {
-        const char *e = getenv("RMAV_SPLIT");
-        return e ? atoi(e) : -1;
-    }();
-    static const int slice_forced = [] {
-        const char *e = getenv("RMAV_SLICE");
-        return e ? atoi(e) : -1;
-    }();
+    const int forced = h->tune[RMAV_TUNE_SPLIT], slice_forced = h->tune[RMAV_TUNE_SLICE];
     *slices = 1;
-    static const int min_steps = [] {
-        const char *e = getenv("RMAV_SPLIT_MIN_STEPS");
-        return e ? atoi(e) : 2;   // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
-    }();
+    // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
+    const int min_steps = h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] > 0 ? h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] : 2;
     if (a.n_steps < min_steps || h->kind > RMAV_QUAD3D_SL) return false;
     const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
     if (forced == 0) return false;
@@ -385,21 +378,19 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
 
-// n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_STEP_KERNEL=0 falls back to k_rollout)
+// n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_TUNE_STEP_KERNEL = 0 falls back to k_rollout)
 template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctrl) {
+    if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;   // the armed launch's snapshot is no longer the latest
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
-    else hipLaunchKernelGGL((k_step<K, false>), grid_for(h->n), dim3(block_size()), 0, h->stream, a, p, pc);
+    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
+    else hipLaunchKernelGGL((k_step<K, false>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
 
 int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
-    static const bool step_kernel = [] {
-        const char *e = getenv("RMAV_STEP_KERNEL");
-        return !(e && atoi(e) == 0);
-    }();
+    const bool step_kernel = h->tune[RMAV_TUNE_STEP_KERNEL] != 0;
     if (step_kernel && a.n_steps == 1 && (mode == RMAV_ACT_BUFFER || mode == ACT_BUFFER_CTRL) && h->kind != RMAV_REINMAV) {
         const bool ctrl = mode == ACT_BUFFER_CTRL;
         switch (h->kind) {
@@ -446,7 +437,7 @@ RolloutArgs base_args(rmav_handle h) {
 int launch_reset(rmav_handle h, float *obs_dev, int layout) {
     const uint32_t fl = (h->flags & F_TRACK) | (layout == RMAV_AOS ? F_AOS : 0u);
 #define RMAV_RESET_CASE(KIND)                                                                      \
-    hipLaunchKernelGGL((k_reset<KIND>), grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,      \
+    hipLaunchKernelGGL((k_reset<KIND>), grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,      \
                        h->n, h->reset_cnt, h->ep_ret, h->ep_len, obs_dev, h->seed, h->env_base, fl)
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_RESET_CASE(QUAD2D); break;
@@ -464,7 +455,7 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
     const uint32_t fl = (layout == RMAV_AOS ? F_AOS : 0u);
     const ParamsT<double> pc = derive<double>(h->params);
 #define RMAV_CTRL_CASE(KIND)                                                                       \
-    hipLaunchKernelGGL((k_control<KIND>), grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,    \
+    hipLaunchKernelGGL((k_control<KIND>), grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,    \
                        h->n, act_dev, fl, pc, h->pe[0], h->pe[1], h->pe[2])
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_CTRL_CASE(QUAD2D); break;
@@ -472,7 +463,7 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
     case RMAV_QUAD3D: RMAV_CTRL_CASE(QUAD3D); break;
     case RMAV_QUAD3D_SL: RMAV_CTRL_CASE(QUAD3D_SL); break;
     case RMAV_REINMAV:
-        hipLaunchKernelGGL(k_control_reinmav, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,
+        hipLaunchKernelGGL(k_control_reinmav, grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,
                            h->env_time, h->n, act_dev, fl, derive_reinmav(h->params));
         break;
     }
@@ -638,6 +629,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     h->env_base = env_id_base;
     h->flags = flags;
     h->params = pr;
+    for (int i = 0; i < RMAV_TUNE_COUNT; ++i) h->tune[i] = -1;
     if (hip_stream) {
         // (void*)1 names the legacy default stream, whose real handle is 0: use that (some runtime entry points -
         // hipEventRecord - do not accept the hipStreamLegacy constant)
@@ -730,6 +722,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
 
 int rmav_destroy(rmav_handle h) {
     if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (h->xchg.comm && h->xchg.comm->armed_by == h) h->xchg.comm->armed_by = nullptr;
     DeviceGuard guard(h->device);
     (void)hipStreamSynchronize(h->stream);
     free_all(h);
@@ -796,6 +789,19 @@ int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem) {
         return fail(RMAV_ERR_ALLOC, "device allocation failed");
     }
     return copy_in(h, h->pe[which], values, (size_t)h->n, mem);
+}
+
+int rmav_set_tuning(rmav_handle h, int key, int value) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (key < 0 || key >= RMAV_TUNE_COUNT) return fail(RMAV_ERR_INVALID, "unknown tuning key %d", key);
+    h->tune[key] = value;
+    return RMAV_OK;
+}
+int rmav_get_tuning(rmav_handle h, int key, int *value_out) {
+    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (key < 0 || key >= RMAV_TUNE_COUNT || !value_out) return fail(RMAV_ERR_INVALID, "unknown tuning key %d or NULL out", key);
+    *value_out = h->tune[key];
+    return RMAV_OK;
 }
 
 int64_t rmav_num_envs(rmav_handle h) {
@@ -886,6 +892,7 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
     if (layout == RMAV_AOS) a.flags |= F_AOS;
     a.ctrl_out = d_ctrl;
     const int kmode = d_ctrl ? (int)ACT_BUFFER_CTRL : action_mode;
+    h->xchg.allow = fused != 0;   // one fused launch may carry an armed exchange's snapshot; the fused = 0 loop may not
     if (fused) {
         a.n_steps = n_steps;
         a.act_in = d_act_in;
@@ -988,6 +995,7 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
     a.logp_out = logp_out;
     a.val_out = value_out;
     const int kmode = precision == RMAV_POLICY_FP32 ? (int)RMAV_ACT_POLICY : precision == RMAV_POLICY_BF16_MFMA ? (int)RMAV_ACT_POLICY_BF16 : (int)ACT_POLICY_F32M;
+    h->xchg.allow = true;
     if (int rc = launch_rollout(h, kmode, a)) return rc;
     h->t += (uint64_t)n_steps;
     return RMAV_OK;
@@ -1025,12 +1033,12 @@ int rmav_get_state(rmav_handle h, float *out, int mem, int layout) {
     const size_t cnt = (size_t)h->n * nS;
     if (layout == RMAV_SOA) return copy_out(h, (const float *)h->state, out, cnt, mem);
     if (mem == RMAV_DEVICE) {
-        hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state, out, h->n, nS);
+        hipLaunchKernelGGL(k_soa_to_aos, grid_for(h), dim3(block_size(h)), 0, h->stream, h->state, out, h->n, nS);
         HIP_TRY(hipGetLastError());
         return RMAV_OK;
     }
     if (int rc = ensure_scratch(h, cnt * sizeof(float))) return rc;
-    hipLaunchKernelGGL(k_soa_to_aos, grid_for(h->n), dim3(block_size()), 0, h->stream, h->state,
+    hipLaunchKernelGGL(k_soa_to_aos, grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,
                        (float *)h->scratch, h->n, nS);
     HIP_TRY(hipGetLastError());
     return copy_out(h, (const float *)h->scratch, out, cnt, RMAV_HOST);
@@ -1049,7 +1057,7 @@ int rmav_set_state(rmav_handle h, const float *in, int mem, int layout) {
         HIP_TRY(hipMemcpyAsync(h->scratch, in, cnt * sizeof(float), hipMemcpyHostToDevice, h->stream));
         src = (const float *)h->scratch;
     }
-    hipLaunchKernelGGL(k_aos_to_soa, grid_for(h->n), dim3(block_size()), 0, h->stream, src, h->state, h->n, nS);
+    hipLaunchKernelGGL(k_aos_to_soa, grid_for(h), dim3(block_size(h)), 0, h->stream, src, h->state, h->n, nS);
     HIP_TRY(hipGetLastError());
     if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
     return RMAV_OK;
@@ -1263,23 +1271,19 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     // default mapping, 189 us with GPU_MAX_HW_QUEUES=8, 93 us with 2).  Priority levels have queues of their own.
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    static const bool plain = [] { const char *e2 = getenv("RMAV_COMM_STREAM_PRIORITY"); return e2 && atoi(e2) == 0; }();
-    hipError_t e = plain ? hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)
-                         : hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
-    {
-        const char *ed = getenv("RMAV_EXCHANGE_DEPTH");
-        c->depth = ed ? atoi(ed) : kExchangeDepth;
-        if (c->depth < 2) c->depth = 2;
-        if (c->depth > kExchangeDepth) c->depth = kExchangeDepth;
-    }
+    hipError_t e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi);
+    c->depth = kExchangeDepth;
     for (int k = 0; k < kExchangeDepth && e == hipSuccess; ++k) {
-        // device-scope release: these events only order streams of this GPU (RMAV_DBG_EVENT_FLAGS overrides, diagnostic)
-        static const unsigned evf = [] {
-            const char *e2 = getenv("RMAV_DBG_EVENT_FLAGS");
-            return e2 ? (unsigned)strtoul(e2, nullptr, 0) : (unsigned)(hipEventDisableTiming | hipEventReleaseToDevice);
-        }();
+        // device-scope release: these events only order streams of this GPU
+        const unsigned evf = hipEventDisableTiming | hipEventReleaseToDevice;
         e = hipEventCreateWithFlags(&c->ready[k], evf);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[k], evf);
+    }
+    // the word k_wait_arrivals raises when it gives up on an armed launch (pinned host memory: the host reads it for free)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->timeout_flag, sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->timeout_flag = 0;
+        e = hipHostGetDevicePointer((void **)&c->timeout_flag_dev, c->timeout_flag, 0);
     }
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -1292,9 +1296,7 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     // compute stream one tiny launch (hipStreamWriteValue32 in its place: +3 us per post, measured).  Falls back to the event when the device cannot wait on memory.
     int can_wait = 0;
     (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, device);
-    const char *e2 = getenv("RMAV_EXCHANGE_EVENTS");   // =1: hand over with events (diagnostic A/B)
-    const bool no_signal = e2 && atoi(e2) == 1;
-    if (can_wait && !no_signal) {
+    if (can_wait) {
         if (hipExtMallocWithFlags((void **)&c->flag, 8, hipMallocSignalMemory) != hipSuccess) {
             (void)hipGetLastError();
             c->flag = nullptr;
@@ -1320,7 +1322,13 @@ int rmav_comm_destroy(rmav_comm c) {
     }
     if (c->flag) (void)hipFree(c->flag);
     if (c->arrive) (void)hipFree(c->arrive);
+    if (c->timeout_flag) (void)hipHostFree(c->timeout_flag);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->armed_by && c->armed_by->magic == kMagic && c->armed_by->xchg.comm == c) {
+        // a handle still points at this communicator: disarm it, or its next rollout would dereference freed memory
+        c->armed_by->xchg.armed = c->armed_by->xchg.fired = false;
+        c->armed_by->xchg.comm = nullptr;
+    }
     c->magic = 0;
     delete c;
     return RMAV_OK;
@@ -1398,12 +1406,10 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
     // even started when the host gets here, and a device-side wait (hipStreamWaitEvent = a barrier packet in the COMPUTE
     // stream) was inserted in front of nearly every pack: +8 us per rollout, measured.  So the HOST waits instead - back
     // pressure that bounds its lead to `depth` rollouts (>= 0.5 ms of queued GPU work at depth 8) and puts nothing into
-    // the compute stream.  RMAV_EXCHANGE_DEVICE_WAIT=1: the device-side wait (diagnostic A/B).
+    // the compute stream.
     if (c->used[k] && hipEventQuery(c->done[k]) != hipSuccess) {
         (void)hipGetLastError();
-        static const bool device_wait = [] { const char *e = getenv("RMAV_EXCHANGE_DEVICE_WAIT"); return e && atoi(e) == 1; }();
-        if (device_wait) HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
-        else HIP_TRY(hipEventSynchronize(c->done[k]));
+        HIP_TRY(hipEventSynchronize(c->done[k]));
     }
     *cmax_out = cmax;
     *slot_out = k;
@@ -1419,7 +1425,9 @@ int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total) {
     if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) return rc;
     h->xchg.armed = true;
     h->xchg.fired = false;
+    h->xchg.stale = false;
     h->xchg.comm = c;
+    c->armed_by = h;
     h->xchg.slot = k;
     h->xchg.cmax = cmax;
     h->xchg.seq = (uint32_t)(c->posts + 1);
@@ -1441,13 +1449,18 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
         cmax = h->xchg.cmax;
         k = h->xchg.slot;
         h->xchg.armed = false;
+        h->xchg.comm = nullptr;
+        c->armed_by = nullptr;
     } else if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) {
         return rc;
     }
-    if (armed && h->xchg.fired) {
-        // the rollout launch itself wrote the snapshot and its wavefronts' arrival words: nothing enters the compute stream
+    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an earlier armed exchange never saw its rollout launch complete");
+    if (armed && h->xchg.fired && !h->xchg.stale) {
+        // the rollout launch itself wrote the snapshot and its wavefronts' arrival words: nothing enters the compute stream.
+        // The wait is bounded (kArrivalWaitTicks of the 100 MHz clock): if the armed launch never completes, the waiter raises
+        // timeout_flag and lets the gather go ahead, so the communicator's stream cannot hang for ever behind it.
         hipLaunchKernelGGL(k_wait_arrivals, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->arrive, h->xchg.expected,
-                           h->xchg.seq);
+                           h->xchg.seq, kArrivalWaitTicks, c->timeout_flag_dev);
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
@@ -1463,20 +1476,6 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ready[k], 0));
         }
     }
-    static const int dbg = [] { const char *e = getenv("RMAV_DBG_EXCHANGE"); return e ? atoi(e) : 0; }();
-    if (dbg == 1) {   // diagnostic: no collective at all
-    } else if (dbg == 2) {   // diagnostic: a plain copy instead of the RCCL kernel (single rank only)
-        HIP_TRY(hipMemcpyAsync(c->recv[k], c->send[k], (size_t)(2 * cmax) * sizeof(int32_t), hipMemcpyDeviceToDevice, c->stream));
-    } else if (dbg == 3) {
-        // diagnostic: a stand-in for the kernel of a multi-GPU ring all-gather that waits for its peers - RMAV_DBG_OCC_WGS
-        // workgroups of 256 threads with RMAV_DBG_OCC_LDS bytes of LDS hold CU slots for RMAV_DBG_OCC_US microseconds
-        static const int wgs = [] { const char *e = getenv("RMAV_DBG_OCC_WGS"); return e ? atoi(e) : 16; }();
-        static const int lds = [] { const char *e = getenv("RMAV_DBG_OCC_LDS"); return e ? atoi(e) : 32768; }();
-        static const int us = [] { const char *e = getenv("RMAV_DBG_OCC_US"); return e ? atoi(e) : 80; }();
-        hipLaunchKernelGGL(k_occupy, dim3(wgs), dim3(256), (size_t)lds, c->stream, (uint64_t)us * 100ull /* 100 MHz counter */,
-                           (uint32_t *)c->recv[k]);
-        HIP_TRY(hipGetLastError());
-    } else
     RCCL_TRY(R->AllGather(c->send[k], c->recv[k], (size_t)(2 * cmax), ncclInt32, c->comm, c->stream));
     HIP_TRY(hipEventRecord(c->done[k], c->stream));
     c->used[k] = true;
@@ -1490,11 +1489,35 @@ int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, flo
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
     if (c->posts == 0 || cmax != c->cmax) return fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
+    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
     const int k = (c->posts - 1) % c->depth;
     HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
                        (const int32_t *)c->recv[k], n_total, (int32_t)c->world, cmax, returns_out, lengths_out);
     HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+int rmav_allgather_stats_wait(rmav_comm c, double timeout_s) {
+    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (c->posts == 0) return RMAV_OK;
+    DeviceGuard guard(c->device);
+    const int k = (c->posts - 1) % c->depth;
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const hipError_t e = hipEventQuery(c->done[k]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return fail(RMAV_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+        (void)hipGetLastError();
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (timeout_s >= 0 && (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
+            return fail(RMAV_ERR_TIMEOUT, "the posted exchange did not complete within %.3f s", timeout_s);
+        timespec nap = {0, 50000};
+        nanosleep(&nap, nullptr);
+    }
+    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
     return RMAV_OK;
 }
 

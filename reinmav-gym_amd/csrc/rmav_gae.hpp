@@ -150,29 +150,23 @@ __global__ void k_signal(uint32_t *flag, uint32_t seq) {
 // post's) in its arrival word: one workgroup polling `count` words with agent-scope loads.  hipStreamWaitValue32 is a
 // spinning one-wavefront kernel of the runtime as well (__amd_rocclr_streamOpsWait in the kernel trace); this one waits
 // for the rollout kernel's own wavefronts, so the compute stream needs no pack and no signal kernel.
-__global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, uint32_t count, uint32_t seq) {
+__global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, uint32_t count, uint32_t seq,
+                                                       unsigned long long max_ticks, uint32_t *timeout_flag) {
+    // Bounded: if the armed launch never publishes (its launch failed after the host armed it, or the device was reset under
+    // it), give up after max_ticks of the constant 100 MHz clock, raise *timeout_flag (pinned host memory: rmav_allgather_stats_*
+    // then return RMAV_ERR_TIMEOUT) and let the stream go on - a communicator stream that spins for ever would also block
+    // every other rank's collective.
+    const unsigned long long t0 = wall_clock64();
     for (;;) {
         int ok = 1;
         for (uint32_t i = threadIdx.x; i < count; i += 256u)
             ok &= (int32_t)(__hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0;
         if (__syncthreads_and(ok)) break;
+        if (__syncthreads_or(wall_clock64() - t0 > max_ticks)) {
+            if (threadIdx.x == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
         __builtin_amdgcn_s_sleep(32);
-    }
-}
-// diagnostic stand-in for a collective's kernel (RMAV_DBG_EXCHANGE=3): workgroups that hold their CU slots - threads,
-// registers and `extern` LDS - for `cycles` ticks of the 100 MHz wall clock without touching memory, like a ring all-gather waiting for
-// its peers.  Used to measure how the rollout kernels tolerate a co-resident communication kernel on ONE GPU.
-__global__ void k_occupy(uint64_t cycles, uint32_t *sink) {
-    extern __shared__ uint32_t occ_lds[];
-    const uint64_t t0 = wall_clock64();   // constant 100 MHz counter
-    uint32_t spins = 0;
-    while (wall_clock64() - t0 < cycles) {
-        __builtin_amdgcn_s_sleep(8);
-        ++spins;
-    }
-    if (cycles == ~0ull) {   // never: keeps the LDS allocation and the loop alive
-        occ_lds[threadIdx.x] = spins;
-        sink[0] = occ_lds[0];
     }
 }
 // recv = [world][2][cmax] -> returns_out / lengths_out [n_total] in global env order (rank r owns

@@ -24,7 +24,8 @@ ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY, ACT_POLICY_BF16 = 0, 1, 2, 3
 POLICY_FP32, POLICY_BF16_MFMA, POLICY_FP32_MFMA = 0, 1, 2
 INT_EULER, INT_RK4 = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC = 0, -1, -2, -3, -4
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5
+TUNE = {"split": 0, "slice": 1, "store_policy": 2, "split_group": 3, "block": 4, "step_kernel": 5, "split_min_steps": 6}
 COMM_ID_BYTES = 128
 
 
@@ -80,6 +81,8 @@ PROTOTYPES = {
     "rmav_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "rmav_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rmav_set_env_param": (C.c_int, [C.c_void_p, C.c_int, _fp, C.c_int]),
+    "rmav_set_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rmav_get_tuning": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "rmav_num_envs": (C.c_int64, [C.c_void_p]),
     "rmav_sync": (C.c_int, [C.c_void_p]),
     "rmav_reset": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
@@ -102,6 +105,7 @@ PROTOTYPES = {
     "rmav_allgather_stats_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rmav_allgather_stats_arm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rmav_allgather_stats_result": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
+    "rmav_allgather_stats_wait": (C.c_int, [C.c_void_p, C.c_double]),
     "rmav_pack_stats": (C.c_int, [C.c_void_p, C.c_int64, _vp]),
     "rmav_get_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),
     "rmav_set_state": (C.c_int, [C.c_void_p, _fp, C.c_int, C.c_int]),

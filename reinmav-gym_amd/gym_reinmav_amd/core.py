@@ -87,6 +87,12 @@ class BatchedQuadrotor:
     def sync(self):
         A.check(self._lib.rmav_sync(self._h))
 
+    def set_tuning(self, **kv):
+        """Explicit overrides of the launch heuristics (``rmav_set_tuning``): split, slice, store_policy, split_group,
+        block, step_kernel, split_min_steps; -1 = automatic.  Results never depend on them."""
+        for k, v in kv.items():
+            A.check(self._lib.rmav_set_tuning(self._h, A.TUNE[k], int(v)))
+
     @property
     def params(self) -> A.Params:
         p = A.Params()

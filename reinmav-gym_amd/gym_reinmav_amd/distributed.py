@@ -148,9 +148,12 @@ class NativeStatsExchange:
     15 us of host time per post against ~100 us for ``all_gather_into_tensor`` behind Python, which matters when one
     exchange follows every ~100 us rollout launch.
 
-    ``connect_timeout_s``: create the communicator and run one complete exchange on a helper thread and give up
-    (``TimeoutError``; the communicator is abandoned, never destroyed) if that takes longer - a caller that can fall back
-    to ``EpisodeStatsExchange`` is then not stuck behind a collective that never completes."""
+    ``connect_timeout_s``: bound the set-up.  ``rmav_comm_create`` (RCCL's rendezvous) runs on a helper thread that
+    touches nothing but the communicator; then ONE complete exchange is posted and awaited on the HOST with a deadline
+    (``rmav_allgather_stats_wait`` polls the gather's completion event), and only after it has completed is anything
+    enqueued on the env's stream.  On ``TimeoutError`` the env and its stream are therefore exactly as before - a caller
+    can fall back to ``EpisodeStatsExchange`` on the same env - and the communicator is abandoned (never destroyed: a
+    thread or a collective may still be inside RCCL)."""
 
     def __init__(self, env, n_total: int, group=None, connect_timeout_s: Optional[float] = None):
         import ctypes as C
@@ -182,35 +185,42 @@ class NativeStatsExchange:
         self.ret = torch.empty(self.n_total, dtype=torch.float32, device=dev)
         self.len = torch.empty(self.n_total, dtype=torch.int32, device=dev)
 
-        def connect():
+        def create():
             A.check(L.rmav_comm_create(C.byref(self._comm), raw, self.rank, self.world, env.device))
-            if connect_timeout_s is not None:   # one whole exchange before anybody relies on it
-                self.post()
-                self.result()
-                torch.cuda.synchronize(dev)
 
         if connect_timeout_s is None:
-            connect()
-        else:
-            import threading
+            create()
+            return
+        import threading
+        import time
 
-            box = []
+        t0 = time.monotonic()
+        box = []
 
-            def target():
-                try:
-                    with torch.cuda.device(dev):
-                        connect()
-                except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
-                    box.append(e)
+        def target():
+            try:
+                with torch.cuda.device(dev):
+                    create()
+            except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+                box.append(e)
 
-            th = threading.Thread(target=target, daemon=True)
-            th.start()
-            th.join(connect_timeout_s)
-            if th.is_alive():
-                self._abandoned = True
-                raise TimeoutError(f"the RCCL communicator / first exchange did not complete in {connect_timeout_s} s")
-            if box:
-                raise box[0]
+        th = threading.Thread(target=target, daemon=True)
+        th.start()
+        th.join(connect_timeout_s)
+        if th.is_alive():
+            self._abandoned = True
+            raise TimeoutError(f"rmav_comm_create (RCCL rendezvous) did not complete in {connect_timeout_s} s")
+        if box:
+            raise box[0]
+        # one whole exchange before anybody relies on it: post (a pack + signal on the env's stream, the gather on the
+        # communicator's own stream), then a HOST-side wait with the rest of the deadline
+        self.post()
+        rc = L.rmav_allgather_stats_wait(self._comm, max(0.5, connect_timeout_s - (time.monotonic() - t0)))
+        if rc == A.ERR_TIMEOUT:
+            self._abandoned = True
+            raise TimeoutError(f"the first exchange did not complete in {connect_timeout_s} s")
+        A.check(rc)
+        self.result()
 
     def arm(self, env=None):
         """Call BEFORE the rollout whose statistics the next post() exchanges: that launch then writes the snapshot itself
@@ -221,6 +231,14 @@ class NativeStatsExchange:
     def post(self, env=None, **_):
         e = env if env is not None else self.env
         self._A.check(self._A.lib().rmav_allgather_stats_post(e._h, self._comm, self.n_total))
+
+    def wait(self, timeout_s: float = -1.0) -> bool:
+        """Host-side bounded wait for the most recent post (touches no stream); False on timeout."""
+        rc = self._A.lib().rmav_allgather_stats_wait(self._comm, float(timeout_s))
+        if rc == self._A.ERR_TIMEOUT:
+            return False
+        self._A.check(rc)
+        return True
 
     def result(self):
         C = self._C

@@ -82,6 +82,7 @@ class NativeQuadrotorEnv(_EnvBase):
 
     def seed(self, seed=None):
         self._seed_value = self._fresh_seed() if seed is None else int(seed)
+        self._ctrl_valid = False
         self._batch.seed(self._seed_value)
         return [self._seed_value]
 
@@ -91,6 +92,8 @@ class NativeQuadrotorEnv(_EnvBase):
 
     def step(self, action):
         self._a[0, :] = action          # casts float64 -> float32, raises on a wrong length like the reference's unpacking
+        if self._hnd is None:
+            raise A.RmavError(A.ERR_INVALID, "step() on a closed env")
         rc = self._step_control(self._hnd, self._pa, self._po, self._pr, self._pd, self._pc, A.HOST, A.AOS)
         if rc < 0:
             A.check(rc)
@@ -106,6 +109,8 @@ class NativeQuadrotorEnv(_EnvBase):
         raise NotImplementedError("rendering (pyglet / vpython in the reference) is outside the GPU hot path")
 
     def close(self):
+        self._hnd = None                # the cached raw handle must not outlive the library's
+        self._ctrl_valid = False
         self._batch.close()
 
     # -- public attributes of the reference ---------------------------------------------------------------
@@ -125,6 +130,7 @@ class NativeQuadrotorEnv(_EnvBase):
 
     @steps_beyond_done.setter
     def steps_beyond_done(self, v):
+        self._ctrl_valid = False
         self._batch.set_sbd(np.array([-1 if v is None else int(v)], dtype=np.int32))
 
     @property

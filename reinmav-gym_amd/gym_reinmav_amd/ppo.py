@@ -37,7 +37,7 @@ class _LinearFM(torch.autograd.Function):
     ``CHUNK`` columns it is a batched 64 x 64 x CHUNK product over hundreds of workgroups plus a small sum."""
 
     CHUNK = 8192
-    _ones: dict = {}
+    _ones = None   # one vector of ones, grown to the largest batch seen (sliced for smaller ones)
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -51,15 +51,17 @@ class _LinearFM(torch.autograd.Function):
         B, C = x.shape[1], _LinearFM.CHUNK
         if B % C == 0 and B > C:
             nb = B // C
-            gw = torch.bmm(gy.view(gy.shape[0], nb, C).transpose(0, 1),            # [nb, out, C]
-                           x.view(x.shape[0], nb, C).permute(1, 2, 0)).sum(0)       # [nb, C, in] -> [out, in]
+            # autograd may hand over a non-contiguous gy (expanded / transposed grads), callers a permuted x
+            gy_c, x_c = gy.contiguous(), x.contiguous()
+            gw = torch.bmm(gy_c.view(gy.shape[0], nb, C).transpose(0, 1),          # [nb, out, C]
+                           x_c.view(x.shape[0], nb, C).permute(1, 2, 0)).sum(0)     # [nb, C, in] -> [out, in]
         else:
             gw = gy @ x.t()
         # bias gradient as a matrix-vector product with ones (the generic row reduction ran at 2.7 TB/s)
-        ones = _LinearFM._ones.get((B, gy.device))
-        if ones is None:
-            ones = _LinearFM._ones[(B, gy.device)] = torch.ones(B, dtype=gy.dtype, device=gy.device)
-        return gx, gw, torch.mv(gy, ones)
+        ones = _LinearFM._ones
+        if ones is None or ones.numel() < B or ones.device != gy.device or ones.dtype != gy.dtype:
+            ones = _LinearFM._ones = torch.ones(B, dtype=gy.dtype, device=gy.device)
+        return gx, gw, torch.mv(gy, ones[:B])
 
 
 class MlpPolicy(torch.nn.Module):
@@ -396,6 +398,18 @@ class PPO:
             p.grad.copy_(flat[o:o + n].view_as(p.grad))
             o += n
 
+    def loss(self, obs, act, logp_old, val_old, adv, ret):
+        """Clipped-surrogate loss of one minibatch (feature-major obs [nS, B], act [nA, B]; the rest [B]);
+        the advantages are normalised over the minibatch as in baselines' ppo2.  -> (loss, pg, vf, ratio)."""
+        a = (adv - adv.mean()) / (adv.std() + 1e-8)
+        mean, v = self.policy(obs)
+        logp = self.policy.log_prob(mean, act)
+        ratio = torch.exp(logp - logp_old)
+        pg = torch.max(-a * ratio, -a * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)).mean()
+        v_clip = val_old + torch.clamp(v - val_old, -self.clip, self.clip)
+        vf = 0.5 * torch.max((v - ret) ** 2, (v_clip - ret) ** 2).mean()
+        return pg + self.vf_coef * vf - self.ent_coef * self.policy.entropy(), pg, vf, ratio
+
     def update(self, ro: RolloutCollector) -> dict:
         T, N = ro.rew.shape
         if ro.rew.is_cuda:   # one HIP launch over the [T][N] trajectory (per-lane reverse scan, csrc/rmav_gae.hpp)
@@ -414,15 +428,7 @@ class PPO:
             perm = torch.randperm(B, device=obs.device)
             for i in range(self.minibatches):
                 idx = perm[i * mb:(i + 1) * mb]
-                a = adv[idx]
-                a = (a - a.mean()) / (a.std() + 1e-8)
-                mean, v = self.policy(obs[:, idx])
-                logp = self.policy.log_prob(mean, act[:, idx])
-                ratio = torch.exp(logp - logp_old[idx])
-                pg = torch.max(-a * ratio, -a * torch.clamp(ratio, 1 - self.clip, 1 + self.clip)).mean()
-                v_clip = val_old[idx] + torch.clamp(v - val_old[idx], -self.clip, self.clip)
-                vf = 0.5 * torch.max((v - ret[idx]) ** 2, (v_clip - ret[idx]) ** 2).mean()
-                loss = pg + self.vf_coef * vf - self.ent_coef * self.policy.entropy()
+                loss, pg, vf, ratio = self.loss(obs[:, idx], act[:, idx], logp_old[idx], val_old[idx], adv[idx], ret[idx])
                 self.opt.zero_grad(set_to_none=True)
                 loss.backward()
                 self._allreduce_grads()

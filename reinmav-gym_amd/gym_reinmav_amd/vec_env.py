@@ -6,11 +6,21 @@ object here: ``reset() -> obs[N,nS]``, ``step_async(actions[N,nA])``, ``step_wai
 dones, infos)`` with auto-reset on done (the returned obs of a finished env is its post-reset obs,
 as in ``DummyVecEnv.step_wait``) and ``info['episode'] = {'r', 'l'}`` for finished envs (what
 ``Monitor`` adds).  Observations stay on the GPU as torch tensors unless ``numpy_io=True``.
+
+The per-step loop of ``gym_reinmav/run.py:190-211`` / ppo2's ``Runner`` calls ``step`` once per env-step, and
+at 65 536 envs the kernel behind it runs ~4.5 us - so the wrapper must cost less than that or it, not the GPU,
+sets the step rate.  The device-tensor path therefore does no per-call allocation, validation chain or ctypes
+boxing: output buffers (and their ``ctypes`` pointers, and the ``bool`` views of ``done``) are prepared ahead
+in blocks, an action tensor that already is float32 / contiguous / on the env's device goes straight to
+``rmav_step`` by its ``data_ptr``, and ``step`` is one ABI call.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
+from . import _abi as A
 from .core import BatchedQuadrotor, torch
 from .spaces import Box
 
@@ -22,6 +32,7 @@ ENV_IDS = {
     "quadrotor3d-slungload-v0": "quad3d_sl",
 }
 _ACTION_BOX = {"reinmav": (0.0, 3.5316), "quad2d": (-10.0, 10.0), "quad2d_sl": (-10.0, 10.0), "quad3d": (0.0, 10.0), "quad3d_sl": (-10.0, 10.0)}
+_BLOCK = 16   # steps of fresh output tensors allocated at a time (one allocation each for obs / rew / done)
 
 
 class QuadrotorVecEnv:
@@ -37,42 +48,79 @@ class QuadrotorVecEnv:
         self.action_space = Box(low=lo, high=hi, shape=(self.env.nA,), dtype=np.float32)
         self.observation_space = Box(low=-10.0, high=10.0, shape=(self.env.nS,), dtype=np.float32)
         self._pending = None
-        dev = not self.numpy_io
         # reuse_buffers=True: step_wait() hands out the env's own output buffers (two sets, alternating), valid
-        # until the step after next - no per-step allocation or copy (device tensors only).  The default returns
-        # fresh arrays every step like baselines' DummyVecEnv (whose Runner keeps the returned reward arrays).
-        self.reuse_buffers = bool(reuse_buffers) and dev
-        self._sets = [(self.env._new((self.num_envs, self.env.nS), np.float32, dev),
-                       self.env._new((self.num_envs,), np.float32, dev),
-                       self.env._new((self.num_envs,), np.uint8, dev)) for _ in range(2 if self.reuse_buffers else 1)]
-        self._flip = 0
+        # until the step after next.  The default returns tensors no later step overwrites, like baselines'
+        # DummyVecEnv (whose Runner keeps the returned reward arrays): slices of blocks of _BLOCK steps.
+        self.reuse_buffers = bool(reuse_buffers) and not self.numpy_io
+        self._step_fn = self.env._lib.rmav_step
+        self._hnd = self.env._h
+        self._act_shape = (self.num_envs, self.env.nA)
+        self._dev = None if self.numpy_io else torch.device("cuda", self.env.device)
+        self._slots, self._cursor = [], 0
+        if self.numpy_io:
+            self._host = (np.empty((self.num_envs, self.env.nS), np.float32), np.empty(self.num_envs, np.float32),
+                          np.empty(self.num_envs, np.uint8))
+        elif self.reuse_buffers:
+            self._slots = self._make_slots(2)
 
+    # ---- output buffers of the device path -------------------------------------------------------------
+    def _make_slots(self, k: int):
+        """k steps' worth of output tensors from three allocations -> [(obs, rew, done_bool, p_obs, p_rew, p_done)]."""
+        n, nS = self.num_envs, self.env.nS
+        obs = torch.empty((k, n, nS), dtype=torch.float32, device=self._dev)
+        rew = torch.empty((k, n), dtype=torch.float32, device=self._dev)
+        done = torch.empty((k, n), dtype=torch.uint8, device=self._dev)
+        ts = self.env._tstream
+        if ts is not None and torch.cuda.current_stream(self._dev) != ts:
+            # the kernels that fill these run on the env's stream: tell the caching allocator, or memory freed on the
+            # allocating stream could be handed out again while a step launch is still writing it
+            for t in (obs, rew, done):
+                t.record_stream(ts)
+        p0, p1, p2 = obs.data_ptr(), rew.data_ptr(), done.data_ptr()
+        # the kernels store exactly 0 or 1 into `done` (csrc/rmav_kernels.hpp), so the bool view needs no conversion launch
+        return [(o, r, d, C.c_void_p(p0 + i * n * nS * 4), C.c_void_p(p1 + i * n * 4), C.c_void_p(p2 + i * n))
+                for i, (o, r, d) in enumerate(zip(obs.unbind(0), rew.unbind(0), done.view(torch.bool).unbind(0)))]
+
+    def _next_slot(self):
+        if self.reuse_buffers:
+            self._cursor ^= 1
+            return self._slots[self._cursor]
+        if self._cursor == len(self._slots):
+            self._slots, self._cursor = self._make_slots(_BLOCK), 0
+        s = self._slots[self._cursor]
+        self._cursor += 1
+        return s
+
+    # ---- VecEnv ---------------------------------------------------------------------------------------
     def reset(self):
         return self.env.reset(layout="aos", device_out=not self.numpy_io)
 
     def step_async(self, actions):
         if self.numpy_io:
-            actions = np.asarray(actions, dtype=np.float32)
-        # enqueue on the env's stream; device outputs are filled asynchronously
-        if self.reuse_buffers or self.numpy_io:
-            out = self._sets[self._flip]
-            if self.reuse_buffers:
-                self._flip ^= 1
-        else:   # fresh tensors every step (DummyVecEnv semantics): the kernel writes straight into them, no copies
-            out = (self.env._new((self.num_envs, self.env.nS), np.float32, True),
-                   self.env._new((self.num_envs,), np.float32, True), self.env._new((self.num_envs,), np.uint8, True))
-        self._pending = self.env.step(actions, layout="aos", out=out)
+            self._pending = self.env.step(np.asarray(actions, dtype=np.float32), layout="aos", out=self._host)
+            return
+        if self._hnd is None:
+            raise A.RmavError(A.ERR_INVALID, "step on a closed QuadrotorVecEnv")
+        if not (type(actions) is torch.Tensor and actions.dtype is torch.float32 and actions.device == self._dev
+                and actions.shape == self._act_shape and actions.is_contiguous()):
+            actions, _ = self.env._in(actions if torch.is_tensor(actions) else torch.as_tensor(
+                np.asarray(actions, dtype=np.float32), device=self._dev), self._act_shape)   # convert / validate / raise
+        slot = self._next_slot()
+        # enqueued on the env's stream; the outputs are filled asynchronously
+        rc = self._step_fn(self._hnd, C.c_void_p(actions.data_ptr()), slot[3], slot[4], slot[5], A.DEVICE, A.AOS)
+        if rc < 0:
+            A.check(rc)
+        self._pending = slot
 
     def step_wait(self):
-        assert self._pending is not None, "step_async() must precede step_wait()"
-        obs, rew, done = self._pending
+        slot = self._pending
+        assert slot is not None, "step_async() must precede step_wait()"
         self._pending = None
         if self.numpy_io:
+            obs, rew, done = slot
             done_b = done.astype(bool)
-            obs, rew = obs.copy(), rew.copy()
-        else:
-            done_b = done.view(torch.bool)      # the kernel writes 0 / 1: a bool view, no conversion launch
-        return obs, rew, done_b, self._infos(done_b)
+            return obs.copy(), rew.copy(), done_b, self._infos(done_b)
+        return slot[0], slot[1], slot[2], (self._infos(slot[2]) if self.dict_infos else ())
 
     def step(self, actions):
         self.step_async(actions)
@@ -90,4 +138,5 @@ class QuadrotorVecEnv:
         return infos
 
     def close(self):
+        self._hnd = None
         self.env.close()

@@ -36,7 +36,19 @@ def test_bench_single_process_line(built):
     assert j["value"] >= 50e6                                    # BASELINE target: >= 50 M env-steps/s on one GPU
     om = j["other_modes"]
     assert "error" not in om, om
-    assert 0.0 < om["step"]["roofline_frac"] <= 1.0 and 0.0 < om["rollout_in_place"]["roofline_frac"] <= 1.0
+    assert 0.0 < om["rollout_in_place"]["roofline_frac"] <= 1.0
+    st = om["step"]["roofline"]                                  # the per-step path carries its own roofline object
+    assert 0.0 < st["frac"] <= 1.0 and st["bytes_per_launch"] == 65536 * 101 and st["bound"] == "hbm"
+    for leg, kind_n in (("c3_shard", 131072 * (64 * 61 + 104)), ("c4", 262144 * (64 * 85 + 152))):   # the other single-GPU configs
+        lr = om[leg]["roofline"]
+        assert lr["bytes_per_launch"] == kind_n and 0.0 < lr["frac"] <= 1.0, (leg, lr)
+        assert om[leg]["finished_episodes"] > 0
+    for actor in ("fp32_valu", "fp32_mfma", "bf16_mfma"):
+        pr = om["policy_rollout"][actor]["roofline"]
+        assert 0.0 < pr["hbm"]["frac"] <= 1.0 and all(0.0 < v["frac"] <= 1.0 for k, v in pr.items())
+    assert j["prewarm_launches"] > 0 and j["prewarm_ms"] == 40.0
+    for path in [j["roofline"]["traffic_source"], st["traffic_source"]]:   # every path the line names exists in the repo
+        assert path is None or os.path.exists(os.path.join(ROOT, path.split(" ")[0])), path
     assert om["gym1"]["us_per_iteration_control_plus_step"] > 0 and om["vecenv"]["fresh_tensors_per_step"]["us_per_step"] > 0
     assert om["policy_rollout"]["fp32_mfma"]["env_steps_per_s"] > om["policy_rollout"]["fp32_valu"]["env_steps_per_s"] > 0
     assert om["policy_rollout"]["bf16_mfma"]["env_steps_per_s"] > 0
@@ -96,3 +108,35 @@ def test_bench_under_torchrun_single_rank_rccl(built):
     assert "all_gather_into_tensor" in j2["config"]["parallelism"]
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j["config"]["gathered_envs_with_a_finished_episode"]
     assert j2["config"]["finished_episodes"] == j["config"]["finished_episodes"]
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_gpus_native_exchange(built):
+    """Needs >= 2 GPUs (self-skips on the 1-GPU test box): bench.py --gpus 2 under torch.distributed.run with the NATIVE
+    exchange (RCCL from librmav.so: armed rollout launches, arrival words, k_wait_arrivals, ncclAllGather over xGMI) -
+    the gathered statistics equal a plain torch.distributed all-gather, and the sharded run finishes exactly the
+    episodes of the unsharded one (RNG keyed by global env id)."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least 2 GPUs")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "40", "--warmup", "10", "--prewarm-ms", "0", "--cpu-seconds", "0", "--no-secondary"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                         "--envs-per-gpu", "65536"] + common, capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-3000:]
+    j2 = _line(r2.stdout)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs-per-gpu", "131072"] + common,
+                        capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    j1 = _line(r1.stdout)
+    assert j2["n_gpus"] == 2 and j2["config"]["envs_total"] == 131072 == j1["config"]["envs_total"]
+    assert "rmav_allgather_stats_post" in j2["config"]["parallelism"], j2["config"]["parallelism"]
+    assert j2["config"]["exchange_equals_plain_all_gather"] is True
+    assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
+    assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
+    assert 0.0 < j2["roofline"]["frac"] <= 1.0

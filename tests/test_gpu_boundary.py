@@ -207,12 +207,44 @@ for kind, n in (('quad3d', 4099), ('quad3d', 200000), ('quad2d_sl', 777), ('quad
     r, l = gathered(env, comm, n)
     assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
     assert (eb['last_length'] > 0).any()
+    # fused = 0 with T > 1 (T single-step launches of the rollout kernel): none of them may take the snapshot - the first one
+    # would freeze the statistics T - 1 steps early (ADVICE r02) - so _post packs after the last step
+    for mode in ('random', 'controller'):
+        A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+        env.rollout(12, mode=mode, fused=False, want=(), device_out=True)
+        eb = env.episode_buffers()
+        A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+        assert L.rmav_allgather_stats_wait(comm, 30.0) == 0
+        r, l = gathered(env, comm, n)
+        assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length']), ('fused=0', mode)
+    # a second fused rollout (or a step) between _arm and _post: the first launch's snapshot is stale, _post packs afresh
+    for second in (lambda: env.rollout(16, mode='random', want=(), device_out=True),
+                   lambda: env.step(np.full((n, env.nA), 9.0, np.float32))):
+        A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+        env.rollout(32, mode='random', want=(), device_out=True)
+        second()
+        eb = env.episode_buffers()
+        A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+        r, l = gathered(env, comm, n)
+        assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length']), 'stale snapshot'
     # more posts than buffer pairs, armed and plain mixed
     for i in range(20):
         if i % 3: A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
         env.rollout(8, mode='random', want=(), device_out=True)
         A.check(L.rmav_allgather_stats_post(env._h, comm, n))
     eb = env.episode_buffers()
+    r, l = gathered(env, comm, n)
+    assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
+    # destroying the communicator while the handle is armed disarms the handle (no dangling pointer in the next rollout)
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+    A.check(L.rmav_comm_destroy(comm))
+    env.rollout(16, mode='random', want=(), device_out=True)
+    env.sync()
+    A.check(L.rmav_comm_unique_id(uid)); comm = C.c_void_p(); A.check(L.rmav_comm_create(C.byref(comm), uid, 0, 1, 0))
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, n))                             # armable again
+    env.rollout(16, mode='random', want=(), device_out=True)
+    eb = env.episode_buffers()
+    A.check(L.rmav_allgather_stats_post(env._h, comm, n))
     r, l = gathered(env, comm, n)
     assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
     A.check(L.rmav_comm_destroy(comm)); env.close()

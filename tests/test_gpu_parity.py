@@ -207,40 +207,33 @@ def test_fused_rollout_equals_single_steps(G, kind, mode, T):
 
 
 @pytest.mark.parametrize("kind,n", [("quad3d_sl", 235931), ("quad2d_sl", 262144), ("quad3d", 131072 + 77)])
-def test_kernel_selection_variants_give_the_same_bits(built, kind, n):
+def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
     """One launch of the one-wavefront kernel, the two-wavefront kernel forced, and two rounds of it over balanced halves
     (the default for random-action slung-load batches of 1.75-2 x the capacity) write the same trajectory, state, reset
-    counters and episode statistics - ragged sizes included.  The selection is read from the environment once per process,
-    hence the subprocesses; each prints a digest."""
-    import subprocess, sys
+    counters and episode statistics - ragged sizes included.  The variant is an explicit per-handle override
+    (rmav_set_tuning), so all four run in this process."""
+    import hashlib
 
-    code = f"""
-import hashlib, sys
-sys.path.insert(0, {os.path.join(ROOT, 'reinmav-gym_amd')!r})
-import numpy as np
-import gym_reinmav_amd as g
-env = g.BatchedQuadrotor({kind!r}, {n}, seed=5, auto_reset=True, track_episodes=True)
-h = hashlib.sha256()
-for _ in range(2):
-    tr = env.rollout(24, mode='random', layout='soa', want=('actions', 'obs', 'rew', 'done'))
-    for k in ('actions', 'obs', 'rew', 'done'):
-        h.update(np.ascontiguousarray(tr[k]).tobytes())
-for a in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
-    h.update(np.ascontiguousarray(a).tobytes())
-eb = env.episode_buffers()
-for k in sorted(eb):
-    h.update(np.ascontiguousarray(eb[k]).tobytes())
-t = env.episode_totals()
-print('DIGEST', h.hexdigest(), t['episodes'], t['length_sum'])
-"""
     digests = {}
-    for name, extra in (("default", {}), ("one wavefront", {"RMAV_SPLIT": "0", "RMAV_SLICE": "0"}),
-                        ("two wavefronts, one launch", {"RMAV_SPLIT": "1", "RMAV_SLICE": "0"}),
-                        ("two wavefronts, sliced", {"RMAV_SLICE": "1"})):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
-        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST")]
-        assert r.returncode == 0 and line, (name, r.stdout[-1500:], r.stderr[-1500:])
-        digests[name] = line[0]
+    for name, tune in (("default", {}), ("one wavefront", {"split": 0, "slice": 0}),
+                       ("two wavefronts, one launch", {"split": 1, "slice": 0}),
+                       ("two wavefronts, sliced", {"slice": 1}),
+                       ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0})):
+        env = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=True)
+        env.set_tuning(**tune)
+        h = hashlib.sha256()
+        for _ in range(2):
+            tr = env.rollout(24, mode="random", layout="soa", want=("actions", "obs", "rew", "done"))
+            for k in ("actions", "obs", "rew", "done"):
+                h.update(np.ascontiguousarray(tr[k]).tobytes())
+        for a in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
+            h.update(np.ascontiguousarray(a).tobytes())
+        eb = env.episode_buffers()
+        for k in sorted(eb):
+            h.update(np.ascontiguousarray(eb[k]).tobytes())
+        t = env.episode_totals()
+        digests[name] = (h.hexdigest(), t["episodes"], t["length_sum"])
+        env.close()
     assert len(set(digests.values())) == 1, digests
 
 
