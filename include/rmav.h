@@ -197,7 +197,8 @@ enum rmav_tuning_key {
     RMAV_TUNE_BLOCK = 4,           /* workgroup size of the one-wavefront kernels: 64 | 128 | 256 */
     RMAV_TUNE_STEP_KERNEL = 5,     /* 0: single-step calls use the rollout kernel at n_steps = 1 instead of k_step */
     RMAV_TUNE_SPLIT_MIN_STEPS = 6, /* shortest fused launch that may use the two-wavefront kernel (default 2) */
-    RMAV_TUNE_COUNT = 7
+    RMAV_TUNE_LEAN = 7,            /* 0: the two-wavefront kernel's memory wavefront uses the generic (pointer-advancing) drain */
+    RMAV_TUNE_COUNT = 8
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);

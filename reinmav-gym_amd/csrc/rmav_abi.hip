@@ -286,6 +286,9 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         if (g < 1) g = 1;
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;
+        // lean addressing in the memory wavefront: feature-major, every trajectory array below 4 GiB (32-bit scalar step offsets)
+        if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * h->n < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
+            a.flags |= F_LEAN;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
                            sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
     } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)

@@ -89,7 +89,9 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = CH * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
 };
-enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u };
+// F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
+// memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
+enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u };
 
 
 struct Totals {
@@ -291,9 +293,12 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     //                     store: actions directly, obs / reward / done from a second LDS tile the integrator
     //                     fills.  It is the only wavefront that ever waits on the memory pipeline.
     //   integrator (wave 0): state in registers, reads actions from LDS, writes its outputs to LDS.
-    // Both tiles are double-buffered; one s_barrier per CH env-steps swaps the halves of both.
-    //   helper:     fill A(0) | B0 | fill A(1)          | B1 | fill A(2), drain O(0) | B2 | ... | B(nc) | drain O(nc-1)
-    //   integrator:            B0 | chunk 0: A(0)->O(0) | B1 | chunk 1: A(1)->O(1)   | B2 | ... | B(nc)
+    // Both tiles are double-buffered; one s_barrier per env-step swaps the halves of both.  The memory wavefront runs TWO
+    // steps ahead with the actions, so that the integrator can fetch A(k+1) from LDS while it integrates step k (the LDS
+    // round trip behind the barrier used to sit on its critical path: ~150 of ~1100 cycles per step):
+    //   helper:     fill A(0), A(1) | B0 |               B0x | fill A(2)                | B1 | fill A(3), drain O(0) | B2 | ... | B(nc) | drain O(nc-1)
+    //   integrator:                   B0 | read A(0)   | B0x | read A(1), A(0) -> O(0)  | B1 | read A(2), A(1) -> O(1) | B2 | ... | B(nc)
+    // (B0x keeps fill A(2) - same half as A(0) - behind the integrator's first read.)
     // Same Philox counters, same arithmetic: same bits as ACT_RANDOM.  Lanes past the end of the batch are clones
     // of env N-1 (as in the MFMA mode) so that every lane of both wavefronts reaches every barrier.
     // ACT_CONTROLLER_SPLIT is the same arrangement without the draws: the integrator evaluates the controller and
@@ -447,6 +452,114 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                     }
                 }
             };
+            // Lean addressing (the common case: feature-major trajectories below 4 GiB per array).  The generic drain above
+            // rebuilds a descriptor per array and step from an advancing 64-bit pointer and tests every optional output with a
+            // scalar branch: ~45 scalar / branch instructions per env-step on a wavefront whose ~7 cycles per issued instruction
+            // ARE the step time (SQ counters, profiles/r02/sq_counters.md: 76 SALU per 64 envs and step for both wavefronts).
+            // Here each array has ONE descriptor for the whole launch - a missing output gets num_records = 0, so the hardware
+            // range check drops its stores and no branch is needed - the component offsets q * 4N sit in vector registers
+            // (computed once), and a step advances one scalar offset per array.
+            if ((a.flags & F_LEAN) != 0) {
+                static_assert(CH == 1, "one env-step per hand-over");
+                constexpr int NQ = NS > NA ? NS : NA;
+                uint32_t voff[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) voff[q] = off + (uint32_t)q * col;
+                const rsrc_t rA = a.act_out ? make_rsrc(a.act_out) : make_rsrc_bounded(a.state, 0u);
+                const rsrc_t rO = a.obs_out ? make_rsrc(a.obs_out) : make_rsrc_bounded(a.state, 0u);
+                const rsrc_t rR = a.rew_out ? make_rsrc(a.rew_out) : make_rsrc_bounded(a.state, 0u);
+                const rsrc_t rD = a.done_out ? make_rsrc(a.done_out) : make_rsrc_bounded(a.state, 0u);
+                const uint32_t sA = (uint32_t)NA * col, sO = (uint32_t)NS * col, sR = col, sD = (uint32_t)n;
+                auto drain_l = [&](int32_t k) {   // obs / reward / done (and the controller's action) of step k: LDS -> trajectory
+                    const float *row = lds_p + ST_::A_WORDS + (k & 1) * ST_::O_HALF + lane;
+                    float o[NS];
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) o[q] = row[q * 64];
+                    const float rw = row[ST_::REW], dn = row[ST_::DONE];
+                    if constexpr (!DRAWS) {
+                        float av[NA];
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) av[q] = row[ST_::ACT + q * 64];
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(rA, voff[q], (uint32_t)k * sA, av[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(rO, voff[q], (uint32_t)k * sO, o[q]);
+                    buf_st_aux<AUX>(rR, off, (uint32_t)k * sR, rw);
+                    __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(dn != 0.0f ? 1 : 0), rD, li, (uint32_t)k * sD, 0);
+                };
+                if constexpr (MODE == ACT_BUFFER_SPLIT) {
+                    constexpr int D = RMAV_BUF_PREFETCH;
+                    const rsrc_t rI = make_rsrc(a.act_in);
+                    float pre[D][NA];
+                    auto issue = [&](int32_t k, float (&dst)[NA]) {
+                        if (k < T) {
+#pragma unroll
+                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(rI, voff[q], (uint32_t)k * sA);
+                        }
+                    };
+                    auto put = [&](int32_t c, const float (&src)[NA]) {
+                        float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) buf[q * 64] = src[q];
+                    };
+#pragma unroll
+                    for (int d = 0; d < D; ++d) issue(d, pre[d]);
+                    put(0, pre[0]);
+                    issue(D, pre[0]);
+                    put(1, pre[1 % D]);
+                    issue(D + 1, pre[1 % D]);
+                    __syncthreads();                               // B0
+                    __syncthreads();                               // B0x
+                    for (int32_t cb = 1; cb < nc; cb += D) {
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {              // step c + 1 = cb + d + 1 lives in slot (2 + d) % D: static register indices
+                            const int32_t c = cb + d;
+                            if (c < nc) {                          // wave- and workgroup-uniform
+                                put(c + 1, pre[(2 + d) % D]);
+                                issue(c + 1 + D, pre[(2 + d) % D]);
+                                if (c >= 2) drain_l(c - 2);
+                                __syncthreads();                   // Bc
+                            }
+                        }
+                    }
+                } else {
+                    auto fill_l = [&](int32_t k) {   // actions of step k: draw, hand over, write the action trajectory
+                        float *buf = lds_p + (k & 1) * ST_::A_HALF + lane;
+                        float act[NA];
+                        random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) buf[q * 64] = act[q];
+#pragma unroll
+                        for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(rA, voff[q], (uint32_t)k * sA, act[q]);
+                    };
+                    if constexpr (DRAWS) {
+                        fill_l(0);
+                        if (nc >= 2) fill_l(1);
+                    }
+                    __syncthreads();                                   // B0
+                    if constexpr (DRAWS) __syncthreads();              // B0x
+                    if (nc >= 2) {
+                        if constexpr (DRAWS) {
+                            if (nc >= 3) fill_l(2);
+                        }
+                        __syncthreads();                               // B1
+                    }
+                    for (int32_t c = 2; c + 1 < nc; ++c) {             // steady state: no guards, no optional-output branches
+                        if constexpr (DRAWS) fill_l(c + 1);
+                        drain_l(c - 2);
+                        __syncthreads();                               // Bc
+                    }
+                    if (nc >= 3) {                                     // c = nc - 1: nothing left to draw
+                        drain_l(nc - 3);
+                        __syncthreads();                               // B(nc - 1)
+                    }
+                }
+                if (nc >= 2) drain_l(nc - 2);
+                __syncthreads();                                   // B(nc)
+                drain_l(nc - 1);
+                return;
+            }
             if constexpr (MODE == ACT_BUFFER_SPLIT) {
                 // The caller's actions come from HBM: fetched D hand-overs ahead into registers (a load issued one hand-over
                 // ahead exposed its ~1 us round trip on every env-step: 71 us per 64-step launch at 65 536 envs instead of 41).
@@ -476,24 +589,33 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 for (int d = 0; d < D; ++d) issue(d, pre[d]);
                 put(0, pre[0]);
                 issue(D, pre[0]);
+                put(1, pre[1 % D]);
+                issue(D + 1, pre[1 % D]);
                 __syncthreads();                               // B0
+                __syncthreads();                               // B0x
                 for (int32_t cb = 1; cb < nc; cb += D) {
 #pragma unroll
-                    for (int d = 0; d < D; ++d) {              // step c = cb + d lives in slot (1 + d) % D: static register indices
+                    for (int d = 0; d < D; ++d) {              // step c + 1 = cb + d + 1 lives in slot (2 + d) % D: static register indices
                         const int32_t c = cb + d;
                         if (c < nc) {                          // wave- and workgroup-uniform
-                            put(c, pre[(1 + d) % D]);
-                            issue(c + D, pre[(1 + d) % D]);
+                            put(c + 1, pre[(2 + d) % D]);
+                            issue(c + 1 + D, pre[(2 + d) % D]);
                             if (c >= 2) drain(c - 2);
                             __syncthreads();                   // Bc
                         }
                     }
                 }
             } else {
-                if constexpr (DRAWS) fill(0);
+                if constexpr (DRAWS) {
+                    fill(0);
+                    if (nc >= 2) fill(1);
+                }
                 __syncthreads();                                   // B0
+                if constexpr (DRAWS) __syncthreads();              // B0x
                 for (int32_t c = 1; c < nc; ++c) {
-                    if constexpr (DRAWS) fill(c);
+                    if constexpr (DRAWS) {
+                        if (c + 1 < nc) fill(c + 1);
+                    }
                     if (c >= 2) drain(c - 2);
                     __syncthreads();                               // Bc
                 }
@@ -627,6 +749,17 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             }
         };
         if constexpr (is_buffer(MODE)) load_actions(act_in, act_pre);
+        // two-wavefront modes whose memory wavefront supplies the actions: A(k + 1) is fetched from the hand-over tile while
+        // step k is integrated (see the protocol above)
+        [[maybe_unused]] float act_nx[NA];
+        if constexpr (split_feeds_actions(MODE)) {
+            static_assert(CH == 1, "one env-step per hand-over");
+            __syncthreads();                                       // B0: A(0) and A(1) are in the tile
+            const float *buf = lds_p + (threadIdx.x & 63u);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) act_nx[c] = buf[c * 64];
+            __syncthreads();                                       // B0x (waits for the read above: lgkmcnt(0) precedes s_barrier)
+        }
 
         for (int32_t k = 0; k < a.n_steps; ++k) {
             float act[NA];
@@ -679,11 +812,13 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
             } else if constexpr (split_feeds_actions(MODE)) {
-                if ((k % CH) == 0) __syncthreads();   // B(k / chunk): both tiles swap halves
-                const float *buf = lds_p + ((k / CH) & 1) * SplitTile<NS, NA, true>::A_HALF +
-                                   (k % CH) * (NA * 64) + (threadIdx.x & 63u);
 #pragma unroll
-                for (int c = 0; c < NA; ++c) act[c] = buf[c * 64];
+                for (int c = 0; c < NA; ++c) act[c] = act_nx[c];
+                // A(k + 1): written before B(k), its half is not rewritten before B(k + 1).  (Past the last step this reads a
+                // stale half and the values are never used.)
+                const float *buf = lds_p + ((k + 1) & 1) * SplitTile<NS, NA, true>::A_HALF + (threadIdx.x & 63u);
+#pragma unroll
+                for (int c = 0; c < NA; ++c) act_nx[c] = buf[c * 64];
             } else if constexpr (MODE == ACT_CONTROLLER_SPLIT) {
                 if ((k % CH) == 0) __syncthreads();   // B(k / chunk): the output tile swaps halves
                 env_control<K>(s, pc, act);
@@ -762,7 +897,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 using ST_ = SplitTile<NS, NA, DRAWS>;
                 float *row = lds_p + ST_::A_WORDS + ((k / CH) & 1) * ST_::O_HALF + (k % CH) * ST_::O_ROW +
                              (threadIdx.x & 63u);
-                if (obs_out) {
+                {   // (handed over also when no obs trajectory was asked for: a uniform branch here costs every step)
                     if (aos) {   // env-major for the batch-major drain
                         float *mine = row + (threadIdx.x & 63u) * (ST_::OBS_STRIDE - 1);
 #pragma unroll
@@ -775,11 +910,10 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 row[ST_::REW] = r;
                 row[ST_::DONE] = done ? 1.0f : 0.0f;
                 if constexpr (!DRAWS) {
-                    if (a.act_out) {
 #pragma unroll
-                        for (int c = 0; c < NA; ++c) row[ST_::ACT + c * 64] = act[c];
-                    }
+                    for (int c = 0; c < NA; ++c) row[ST_::ACT + c * 64] = act[c];
                 }
+                if constexpr (split_feeds_actions(MODE)) __syncthreads();   // B(k + 1): O(k) handed over, A(k + 2) may be written
             } else if (obs_out) {
                 if (ST == ST_AOS_LDS && full_wave) {
                     // all 64 lanes are here (full_wave is wave-uniform); LDS executes one wavefront's
@@ -816,7 +950,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 done_out += n;
             }
         }
-        if constexpr (SPLIT) __syncthreads();   // B(nc): the last chunk's outputs are in LDS
+        if constexpr (MODE == ACT_CONTROLLER_SPLIT) __syncthreads();   // B(nc): the last step's outputs are in LDS
 
         if constexpr (is_mfma_policy(MODE)) {   // bootstrap value of the state the rollout ends in
             float x[16], mean[4], val0;

@@ -58,9 +58,15 @@ RMAV_HD float  root(float x)  {
 }
 RMAV_HD float inv_sqrt(float x) {   // 1/sqrt(x)
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (x >= 1.17549435e-38f) return __builtin_amdgcn_rsqf(x);
-#endif
+    // branch-free: a denormal argument is scaled into the normal range first (2^64, exact) and the result scaled back (2^32)
+    // - two selects instead of a divergent branch around the IEEE divide / square root sequence, which sat in the step loop of
+    // every 3-D kind (quat_normalise) as ~10 scalar / branch instructions per env-step
+    const bool tiny = x < 1.17549435e-38f;
+    const float r = __builtin_amdgcn_rsqf(tiny ? x * 18446744073709551616.0f : x);
+    return tiny ? r * 4294967296.0f : r;
+#else
     return 1.0f / __builtin_sqrtf(x);
+#endif
 }
 // fp64 on the device: v_rsq_f64 is a ~single-precision estimate; hipcc's correctly rounded sqrt / divide
 // wrap it in 15-25 more fp64 instructions (half rate).  One Newton step takes the estimate to <= 1e-12
@@ -185,10 +191,8 @@ RMAV_HD void random_action(uint64_t seed, uint64_t env_id, uint64_t t, float lo,
 // Quaternion._normalise(): q/|q| unless |1-|q|^2| < 1e-14 or |q| is 0 (or NaN).
 template <typename R> RMAV_HD void quat_normalise(const R (&q)[4], R (&o)[4]) {
     const R n2 = rfma(q[0], q[0], rfma(q[1], q[1], rfma(q[2], q[2], q[3] * q[3])));
-    R s = R(1);
-    if (!(rabs(R(1) - n2) < R(1e-14))) {
-        if (n2 > R(0)) s = inv_sqrt(n2);   // n2 == 0 (or NaN): left alone, like _normalise
-    }
+    // n2 == 0 (or NaN): left alone, like _normalise.  Written as a select: no divergent branch in the step loop
+    const R s = (!(rabs(R(1) - n2) < R(1e-14)) && n2 > R(0)) ? inv_sqrt(n2) : R(1);
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = q[i] * s;
 }

@@ -6,6 +6,7 @@
 #   bench     bench.py with its defaults, and with the driver's --steps 20 --warmup 5
 #   legs      the other single-GPU BASELINE configs as their own bench lines (C3's shard, C4)
 #   sweep     kernel sweep: kinds x {random, controller} at SWEEP_N (default "65536 131072") -> sweep.md
+#             (SWEEP_TUNE="lean=0" adds rmav_set_tuning overrides; SWEEP_TAG names the output: sweep$SWEEP_TAG.md)
 #   steplat   tools/step_latency.py (single-step launch latency by feature subset)
 #   vecenv    bench.py's vecenv / gym1 legs only
 #   sq        SQ instruction / wait counters of the default bench command (EXTRA= adds bench arguments)
@@ -49,21 +50,22 @@ legs)
   timeout 600 $B --kind quad3d_sl --envs-per-gpu 262144 --steps 500 --warmup 100 --cpu-seconds 0 --no-secondary > $OUT/bench_c4.json 2>/dev/null; line $OUT/bench_c4.json
   ;;
 sweep)
-  : > $OUT/sweep.jsonl
-  for ACT in random controller; do for K in quad3d quad3d_sl quad2d quad2d_sl; do for N in ${SWEEP_N:-65536 131072}; do
+  SW=$OUT/sweep$SWEEP_TAG
+  : > $SW.jsonl
+  for ACT in ${SWEEP_ACT:-random controller}; do for K in ${SWEEP_K:-quad3d quad3d_sl quad2d quad2d_sl}; do for N in ${SWEEP_N:-65536 131072}; do
     S=$(( 65536 * 600 / N + 40 ))
-    timeout 300 $B --kind $K --actions $ACT --envs-per-gpu $N --steps $S --warmup $((S/4)) --cpu-seconds 0 --no-secondary 2>/dev/null | grep '^{' | python -c "
+    timeout 300 $B --kind $K --actions $ACT --envs-per-gpu $N --steps $S --warmup $((S/4)) --cpu-seconds 0 --no-secondary ${SWEEP_TUNE:+--tune $SWEEP_TUNE} 2>/dev/null | grep '^{' | python -c "
 import sys, json
-j = json.loads(sys.stdin.read()); r = j['roofline']; print(json.dumps({'actions': '$ACT', 'kind': '$K', 'n': $N, 'us': r['launch_ms_hip_events'] * 1e3, 'TBps': r['achieved'] / 1e3, 'frac': r['frac']}))" >> $OUT/sweep.jsonl
+j = json.loads(sys.stdin.read()); r = j['roofline']; print(json.dumps({'actions': '$ACT', 'kind': '$K', 'n': $N, 'us': r['launch_ms_hip_events'] * 1e3, 'TBps': r['achieved'] / 1e3, 'frac': r['frac']}))" >> $SW.jsonl
   done; done; done
-  python - $OUT/sweep.jsonl > $OUT/sweep.md <<'PY'
+  python - $SW.jsonl > $SW.md <<'PY'
 import json, sys
 print("| actions | kind | envs | us per 64-step launch | TB/s | frac of 8 TB/s |\n|---|---|---|---|---|---|")
 for l in open(sys.argv[1]):
     r = json.loads(l)
     print(f"| {r['actions']} | {r['kind']} | {r['n']} | {r['us']:.1f} | {r['TBps']:.2f} | {r['frac']:.3f} |")
 PY
-  cat $OUT/sweep.md
+  cat $SW.md
   ;;
 steplat)
   timeout 900 python tools/step_latency.py quad3d > $OUT/step_latency.txt 2>&1; tail -30 $OUT/step_latency.txt
