@@ -536,7 +536,7 @@ def main():
         bytes_launch = algo_bytes * n
         bytes_def = f"{n} envs x {algo_bytes} B (SURVEY 8d: state in/out, action in, reward + done out)"
     achieved = bytes_launch / (kernel_ms * 1e-3) / 1e9  # GB/s, one GPU's dominant kernel
-    tkey = f"{kind}:{args.mode}:{per_launch}:{n}:{'inplace' if (args.in_place or args.mode == 'step') else 'ring'}:{args.actions}:{args.layout}"
+    tkey = f"{kind}:{args.mode}:{per_launch}:{n}:{'inplace' if (args.in_place or args.mode == 'step') else 'ring'}:{args.actions}:{args.layout}" + (f":{args.tune}" if args.tune else "")
     traffic, traffic_src = lookup_traffic(tkey)   # rocprofv3 --pmc bytes per launch of this very command line
 
     if rank == 0:
@@ -576,6 +576,7 @@ def main():
                 "mode": args.mode,
                 "trajectory_layout": args.layout if args.mode == "rollout" else "soa",
                 "trajectory_ring": R,
+                "tune": args.tune,
                 "parallelism": (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one all-gather of "
                                 f"per-env episode stats after every {'rollout launch' if args.exchange_every == 1 else str(args.exchange_every) + ' rollout launches'}, overlapped with the next launch on a second stream: "
                                 f"{exchange_kind})")

@@ -62,8 +62,9 @@
  *   reset : c2 = index of this env's reset (0 for the first),  c3 = (1<<24) | j ; block j supplies
  *           state components 4j..4j+3 as  2*u - 1,  u = (x>>8) * 2^-24          (U[-1,1), as
  *           quadrotor3d.py:184 draws every state component)
- *   action: c2 = low 32 bits of the handle's global step counter t,
- *           c3 = (2<<24) | (bits 32..47 of t) << 8 ; component i = fma(act_hi-act_lo, u_i, act_lo)
+ *   action: block index b = the handle's global step counter t (4-action kinds) or t >> 1 (2-action kinds, which use
+ *           draws 2 (t & 1) and 2 (t & 1) + 1 of the block, i.e. one Philox call per two steps);
+ *           c2 = low 32 bits of b, c3 = (2<<24) | (bits 32..47 of b) << 8 ; component i = fma(act_hi-act_lo, u_i, act_lo)
  *   policy noise (rmav_rollout_policy): as "action" with tag 3; (r0,r1) and (r2,r3) -> Box-Muller:
  *           u1 = ((r>>8)+1) * 2^-24, u2 = (r'>>8) * 2^-24, z = sqrt(-2 ln u1) * (cos, sin)(2 pi u2)
  */
@@ -198,7 +199,8 @@ enum rmav_tuning_key {
     RMAV_TUNE_STEP_KERNEL = 5,     /* 0: single-step calls use the rollout kernel at n_steps = 1 instead of k_step */
     RMAV_TUNE_SPLIT_MIN_STEPS = 6, /* shortest fused launch that may use the two-wavefront kernel (default 2) */
     RMAV_TUNE_LEAN = 7,            /* 0: the two-wavefront kernel's memory wavefront uses the generic (pointer-advancing) drain */
-    RMAV_TUNE_COUNT = 8
+    RMAV_TUNE_STEP_LAZY = 8,       /* 1: k_step loads steps_beyond_done / reset counters only in lanes whose env terminates */
+    RMAV_TUNE_COUNT = 9
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);

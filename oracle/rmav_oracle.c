@@ -446,7 +446,8 @@ float oracle_u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
 /* Counter layout (specification shared with the HIP path, see include/rmav.h "RNG streams"):
  *   key = (seed_lo, seed_hi); ctr = (env_lo, env_hi, c2, (tag << 24) | (hi16 << 8) | block)
  *   reset : tag 1, c2 = episode index, hi16 = 0, block j yields components 4j..4j+3
- *   action: tag 2, c2 = t_lo, hi16 = bits 32..47 of t, block 0 */
+ *   action: tag 2, block index b = t for the 4-action kinds, b = t >> 1 for the 2-action kinds (which take draws 2 (t & 1),
+ *           2 (t & 1) + 1 of the block); c2 = low 32 bits of b, hi16 = bits 32..47 of b */
 void oracle_reset_state(int kind, uint64_t seed, uint64_t env_id, uint32_t episode, float *s_out) {
     int nS = k_state_dim[kind];
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
@@ -464,11 +465,14 @@ void oracle_random_action(int kind, uint64_t seed, uint64_t env_id, uint64_t t, 
                           float *a_out) {
     int nA = k_action_dim[kind];
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
-                       (2u << 24) | ((uint32_t)((t >> 32) & 0xFFFFu) << 8)};
+    const int pairs = nA <= 2;
+    const uint64_t b = pairs ? (t >> 1) : t;
+    uint32_t ctr[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)b,
+                       (2u << 24) | ((uint32_t)((b >> 32) & 0xFFFFu) << 8)};
     uint32_t r[4];
     oracle_philox4x32_10(ctr, key, r);
-    for (int i = 0; i < nA; ++i) a_out[i] = fmaf(hi - lo, oracle_u01(r[i]), lo);
+    const int first = pairs ? 2 * (int)(t & 1u) : 0;
+    for (int i = 0; i < nA; ++i) a_out[i] = fmaf(hi - lo, oracle_u01(r[first + i]), lo);
 }
 
 /* ---- batched drivers ---------------------------------------------------------------------------- */

@@ -240,7 +240,7 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
 // 1024-thread / 160 KiB-LDS limits).  So the rule is capacity, not a tuned constant: two wavefronts iff
 // N <= 16 384 x (pairs that fit one workgroup for this kind and action source).
 template <int K, bool DRAWS> constexpr int split_pairs_max() {
-    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * SplitTile<Dims<K>::NS, Dims<K>::NA, DRAWS>::WORDS));
+    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * SplitTile<Dims<K>::NS, Dims<K>::NA, DRAWS>::WORDS_PER_PAIR));
     constexpr int cap = split_group_cap<K, DRAWS>();   // threads / registers (rmav_kernels.hpp)
     return by_lds < cap ? by_lds : cap;
 }
@@ -290,7 +290,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * h->n < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
             a.flags |= F_LEAN;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
-                           sizeof(float) * Tile::WORDS * g, h->stream, a, p, pc);
+                           sizeof(float) * Tile::WORDS_PER_PAIR * g, h->stream, a, p, pc);
     } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
         const int64_t per_wg = block_size(h) / 2;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds,
@@ -387,6 +387,7 @@ template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctr
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
+    else if (h->tune[RMAV_TUNE_STEP_LAZY] == 1) hipLaunchKernelGGL((k_step<K, false, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     else hipLaunchKernelGGL((k_step<K, false>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;

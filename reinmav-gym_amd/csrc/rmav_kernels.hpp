@@ -67,11 +67,11 @@ constexpr int kSplitChunk = RMAV_SPLIT_CHUNK;
 // but 45 -> 64 us at 65 536 envs, where 8 pairs leave half of the CUs empty and put two integrators on every SIMD.
 // The sweet spot is ONE workgroup per CU: the host launches ceil(N / 16 384) pairs per workgroup (256 workgroups).
 constexpr int kSplitGroupMax = 8;   // 1024 threads
-// ... which caps the kernel at 128 VGPRs.  The integrator of a controller-driven slung-load rollout (fp64 controller
-// on top of the fp64 step) needs more and would spill to scratch: those variants stay at 4 pairs (512 threads).
-template <int K, bool DRAWS> constexpr int split_group_cap() {
-    return (!DRAWS && (K == QUAD2D_SL || K == QUAD3D_SL)) ? 4 : kSplitGroupMax;
-}
+// ... which caps the kernel at 128 VGPRs.  Round 2's controller-driven slung-load integrators (fp64 controller on top of
+// the fp64 step) needed 145-147 and stayed at 4 pairs; with the spare reset state in LDS (SplitTile::SPARE), dirty flags
+// instead of copies of the loaded counters and the 8-coefficient atan2 of the 2-D controller they take 109 / 124, so
+// every kind runs up to 8 pairs (tests/test_resource_usage.py pins the budgets).
+template <int K, bool DRAWS> constexpr int split_group_cap() { return kSplitGroupMax; }
 #ifndef RMAV_KBLOCK
 #define RMAV_KBLOCK 256
 #endif
@@ -88,6 +88,11 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int ACT = DONE + 64;   // actions [c][lane], only when the integrator computes them
     static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = CH * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
+    // + the integrator's spare reset state [c][lane] (drawn once per launch, consumed by the first termination of a lane):
+    // in LDS rather than in NS vector registers that are live through the whole step loop - what the 128-register budget of
+    // 8 pairs per workgroup (1024 threads) was missing for the slung-load kinds.  Laid out after the tiles of all pairs.
+    static constexpr int SPARE = NS * 64;
+    static constexpr int WORDS_PER_PAIR = WORDS + SPARE;
 };
 // F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
 // memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
@@ -524,10 +529,21 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         }
                     }
                 } else {
+                    [[maybe_unused]] uint32_t blk[4] = {0u, 0u, 0u, 0u};   // 2-action kinds: the Philox block of the current pair of steps
+                    [[maybe_unused]] bool blk_valid = false;
                     auto fill_l = [&](int32_t k) {   // actions of step k: draw, hand over, write the action trajectory
                         float *buf = lds_p + (k & 1) * ST_::A_HALF + lane;
                         float act[NA];
-                        random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
+                        const uint64_t t = a.t0 + (uint64_t)k;
+                        if constexpr (action_pairs<K>()) {
+                            if ((t & 1u) == 0 || !blk_valid) {   // wave-uniform: one draw serves steps 2 j and 2 j + 1
+                                random_block<K>(a.seed, env_id, t, blk);
+                                blk_valid = true;
+                            }
+                            action_from_block<K>(blk, t, a.act_lo, a.act_hi, act);
+                        } else {
+                            random_action<K>(a.seed, env_id, t, a.act_lo, a.act_hi, act);
+                        }
 #pragma unroll
                         for (int q = 0; q < NA; ++q) buf[q * 64] = act[q];
 #pragma unroll
@@ -657,8 +673,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         // 1.3 %/step termination rate of random actions).
         int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
         uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
-        const int32_t sb0 = sb;
-        const uint32_t rc0 = rc;
+        bool sb_dirty = false, rc_dirty = false;   // (flags, not copies of the loaded values: two registers less in the step loop)
         const uint64_t env_id = a.env_base + (uint64_t)li;
         // per-env (domain-randomised) constants override the shared kernel arguments for this lane
         typename Env<K>::P pl = p_shared;
@@ -686,10 +701,21 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         // is drawn ONCE up front (all lanes busy, amortised over the launch) and the in-loop reset
         // becomes a predicated register copy.  A second termination of the same env inside one launch
         // falls back to drawing on demand.  Same counters, same bits either way.
-        float spare[NS];
+        // (two-wavefront kernels keep it in LDS - SplitTile::SPARE - so that it does not occupy NS registers in the step loop)
+        [[maybe_unused]] float spare[SPLIT ? 1 : NS];
+        [[maybe_unused]] float *lds_spare = nullptr;
         bool have_spare = false;
         if (K != REINMAV && auto_reset && a.n_steps >= 8) {   // ReinmavEnv.reset() is a no-op (reinmav_env.py:348-351)
-            reset_state<K>(a.seed, env_id, rc, spare);
+            if constexpr (SPLIT) {
+                float sp[NS];
+                reset_state<K>(a.seed, env_id, rc, sp);
+                lds_spare = lds_w + split_g * SplitTile<NS, NA, DRAWS>::WORDS +
+                            (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * SplitTile<NS, NA, DRAWS>::SPARE + (threadIdx.x & 63u);
+#pragma unroll
+                for (int c = 0; c < NS; ++c) lds_spare[c * 64] = sp[c];   // read back by this lane only: no barrier needed
+            } else {
+                reset_state<K>(a.seed, env_id, rc, spare);
+            }
             have_spare = true;
         }
 
@@ -848,6 +874,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 if (done) {
                     r = (sb < 0) ? 1.0f : 0.0f;
                     sb = (sb < 0) ? 0 : sb + 1;
+                    sb_dirty = true;
                 }
             }
             if (act_out) {
@@ -884,12 +911,16 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             if (K != REINMAV && done && auto_reset) {
                 if (have_spare) {
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) s[c] = spare[c];
+                    for (int c = 0; c < NS; ++c) {
+                        if constexpr (SPLIT) s[c] = lds_spare[c * 64];
+                        else s[c] = spare[c];
+                    }
                     have_spare = false;
                 } else {
                     reset_state<K>(a.seed, env_id, rc, s);
                 }
                 rc += 1;
+                rc_dirty = true;
             }
             if constexpr (SPLIT) {
                 // hand obs / reward / done (and the controller's action) to the memory wavefront; it drains this
@@ -988,8 +1019,8 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
         }
         if constexpr (K == REINMAV) a.env_time[li] = tenv;
-        if (sb != sb0) buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-        if (rc != rc0) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
+        if (sb_dirty) buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
+        if (rc_dirty) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     }
 
     if (track) {
@@ -1090,7 +1121,13 @@ __device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_
 //     (in flight beside the state loads) and rewritten by one lane with plain stores; the per-wave sums are
 //     gathered with v_readlane over the set bits of the `done` ballot (usually one bit) instead of shuffle
 //     reductions.  (k_rollout adds to the same slots with atomics; launches are stream-ordered, so they mix.)
-template <int K, bool CTRL>
+//
+// LAZY (rmav_set_tuning(RMAV_TUNE_STEP_LAZY, 1); measured, NOT the default): steps_beyond_done and the reset counter are
+// needed only by lanes whose env terminates (~1.3 % per step), so they are loaded under that predicate AFTER `done` is known -
+// 8 B per env-step less HBM-side traffic (the launch fetches 1.28 x its algorithmic bytes otherwise, of which these two
+// arrays are 0.08), but a dependent memory round trip on the critical path of every wavefront that has a finishing lane
+// (57 % of them), in a kernel whose whole duration is ~1.5 round trips above the launch floor.  profiles/r03/step_lazy_ab.md.
+template <int K, bool CTRL, bool LAZY = false>
 __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                  const ParamsT<double> pc_shared) {
     static_assert(K != REINMAV, "ReinmavEnv steps go through k_rollout");
@@ -1130,8 +1167,12 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         er = buf_ld(make_rsrc(a.ep_ret), off, 0);
         el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
     }
-    int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-    const uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+    int32_t sb = -1;
+    uint32_t rc = 0;
+    if constexpr (!LAZY) {
+        sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+        rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+    }
     typename Env<K>::P pl = p_shared;
     ParamsT<double> pcl = pc_shared;
     if (a.pe[0] || a.pe[1] || a.pe[2]) {
@@ -1145,6 +1186,12 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     float dist = 0.0f;
     bool done;
     Env<K>::step(s, act, pl, dist, done);
+    if constexpr (LAZY) {
+        if (done) {   // only the finishing lanes fetch (one 32-byte sector each instead of the wavefront's 256 bytes)
+            sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+            rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+        }
+    }
     // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
     float r = -dist;
     if (done) {

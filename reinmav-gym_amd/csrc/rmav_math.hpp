@@ -173,18 +173,38 @@ RMAV_HD void reset_state(uint64_t seed, uint64_t env_id, uint32_t reset_idx,
     }
 }
 
+// Random actions (RMAV_ACT_RANDOM).  One Philox4x32-10 call yields four draws: the 4-action kinds use block index t, the
+// 2-action kinds (quadrotor2d, quadrotor2d-slungload) use block index t >> 1 and take the half (t & 1) of it - the draw is
+// the largest single block of a random-action rollout's instruction stream (20 quarter-rate 32x32->64 multiplies per call),
+// and half of it was thrown away for the 2-D kinds.
+template <int K> constexpr bool action_pairs() { return Dims<K>::NA <= 2; }
+template <int K>
+RMAV_HD void random_block(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t (&r)[4]) {
+    const uint64_t b = action_pairs<K>() ? (t >> 1) : t;
+    philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)b,
+                  (2u << 24) | ((uint32_t)((b >> 32) & 0xFFFFu) << 8), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+}
+template <int K>
+RMAV_HD void action_from_block(const uint32_t (&r)[4], uint64_t t, float lo, float hi, float (&a)[Dims<K>::NA]) {
+    // = fma(hi - lo, u01(r), lo) bit for bit: u01 is k * 2^-24 with k < 2^24, both scalings by 2^-24 are exact, and the
+    // fma rounds the same real number once - written this way it is one multiply per draw less
+    const float scale = (hi - lo) * (1.0f / 16777216.0f);
+    // the half of the block as a bit-select on the values ((t & 1) ? r[2 + i] : r[i] is turned into an indexed load from a
+    // copy of r[] in scratch memory by hipcc)
+    const uint32_t m = action_pairs<K>() ? (uint32_t)0 - (uint32_t)(t & 1u) : 0u;
+#pragma unroll
+    for (int i = 0; i < Dims<K>::NA; ++i) {
+        const uint32_t x = action_pairs<K>() ? ((r[i & 1] & ~m) | (r[2 + (i & 1)] & m)) : r[i];
+        a[i] = rfma(scale, (float)(x >> 8), lo);
+    }
+}
 template <int K>
 RMAV_HD void random_action(uint64_t seed, uint64_t env_id, uint64_t t, float lo, float hi,
                            float (&a)[Dims<K>::NA]) {
     uint32_t r[4];
-    philox4x32_10((uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
-                  (2u << 24) | ((uint32_t)((t >> 32) & 0xFFFFu) << 8), (uint32_t)seed,
-                  (uint32_t)(seed >> 32), r);
-    // = fma(hi - lo, u01(r), lo) bit for bit: u01 is k * 2^-24 with k < 2^24, both scalings by 2^-24 are exact, and the
-    // fma rounds the same real number once - written this way it is one multiply per draw less
-    const float scale = (hi - lo) * (1.0f / 16777216.0f);
-#pragma unroll
-    for (int i = 0; i < Dims<K>::NA; ++i) a[i] = rfma(scale, (float)(r[i] >> 8), lo);
+    random_block<K>(seed, env_id, t, r);
+    action_from_block<K>(r, t, lo, hi, a);
 }
 
 // ---- quaternion pieces (pyquaternion semantics the reference relies on) ------------------------
@@ -493,13 +513,49 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
     a[3] = (float)(kw * qe3);
 }
 
+// atan2 for the 2-D controller, absolute error <= 3e-13 (checked against libm over 4e5 random arguments and the axes;
+// the result is multiplied by 1 / tau = 10 and rounded to fp32, so 1e-11 would do).  libm's correctly rounded fp64 atan2 is
+// ~70 fp64 instructions - one IEEE division, a degree-19 polynomial whose 19 coefficients hipcc parks in 38 vector registers
+// - and was half of the controller-driven 2-D step.  Here: ONE reciprocal (v_rcp_f64 + two Newton steps) of a reduced
+// argument |u| <= tan(pi / 8) - atan(t) = pi / 4 + atan((t - 1) / (t + 1)) folded into the quotient's numerator and
+// denominator - and a degree-7 polynomial in u^2 (Chebyshev-node fit of atan(sqrt z) / sqrt z on [0, tan^2(pi / 8)]).
+RMAV_HD double fast_atan2(double y, double x) {
+    const double ax = rabs(x), ay = rabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    const bool big = mn > 0.41421356237309503 * mx;
+    const double num = big ? mn - mx : mn;
+    double den = big ? mn + mx : mx;
+    den = den > 0.0 ? den : 1.0;                           // atan2(0, 0) = 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    const double u = num * rc;
+#else
+    const double u = num / den;
+#endif
+    const double z = u * u;
+    double p = -0.03765508211963291;
+    p = rfma(p, z, 0.0697419671381827);
+    p = rfma(p, z, -0.08992552776397131);
+    p = rfma(p, z, 0.11103456904403586);
+    p = rfma(p, z, -0.14285386554069893);
+    p = rfma(p, z, 0.19999993053581264);
+    p = rfma(p, z, -0.33333333276922894);
+    p = rfma(p, z, 0.9999999999992449);
+    double r = rfma(u, p, big ? 0.7853981633974483 : 0.0);
+    r = ay > ax ? 1.5707963267948966 - r : r;
+    r = x < 0.0 ? 3.141592653589793 - r : r;
+    return y < 0.0 ? -r : r;
+}
+
 // Quadrotor2D.control  quadrotor2d.py:115-138  (= quadrotor2d_slungload.py:156-183)
 template <int NS>
 RMAV_HD void control_2d(const float (&s)[NS], const ParamsT<double> &p, float (&a)[2]) {
     using R = double;
     const R ax = rfma(p.kp, (R)s[0] - p.ref_pos[0], p.kv * ((R)s[3] - p.ref_vel[0]));
     const R ay = rfma(p.kp, (R)s[1] - p.ref_pos[1], p.kv * ((R)s[4] - p.ref_vel[1])) + p.g;  // :130
-    const R th_d = atan2(ay, ax) - R(1.5707963267948966);         // :131
+    const R th_d = fast_atan2(ay, ax) - R(1.5707963267948966);    // :131
     a[1] = (float)(p.neg_inv_tau * ((R)s[2] - th_d));             // :132-133
     a[0] = (float)(p.mass * root(rfma(ax, ax, ay * ay)));   // :134
 }

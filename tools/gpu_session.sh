@@ -77,7 +77,7 @@ sq)
   EXTRA="$EXTRA" bash tools/pmc_sq.sh $TAG/sq > $OUT/sq_counters.txt 2>&1; tail -40 $OUT/sq_counters.txt
   ;;
 prof)
-  bash tools/profile_round.sh $TAG 2>&1 | tail -60
+  bash tools/profile_round.sh $TAG ${ROUND:-r03} 2>&1 | tail -60
   ;;
 dist1)
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --envs-per-gpu 131072 > $OUT/bench_torchrun1_c3shard.json 2> $OUT/bench_dist1.err; echo "rc=$?"; line $OUT/bench_torchrun1_c3shard.json

@@ -9,6 +9,7 @@ import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+ROUND = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(root).replace("prof_", "")   # directory under profiles/ the summary is committed to
 KERNELS = ("k_rollout", "k_step")
 
 
@@ -120,8 +121,9 @@ for d in traces:
     print(f"| {name}{name_note} | {b / 1e6:.1f} MB | {need / 1e6:.1f} MB | {b / need:.3f} | {us:.2f} | {b / us / 1e6:.2f} |" if us else f"| {name} | {b/1e6:.1f} MB | {need/1e6:.1f} MB | {b/need:.3f} | - | - |")
     c = j["config"]
     key = (f"{c['kind']}:{c['mode']}:{c['env_steps_per_launch_per_env']}:{c['envs_per_gpu']}:"
-           f"{'inplace' if (c['trajectory_ring'] == 1 or c['mode'] == 'step') else 'ring'}:{c['actions']}:{c['trajectory_layout']}")
-    traffic[key] = {"bytes": b, "source": f"profiles/{os.path.basename(root).replace('prof_', '')}/rocprofv3_summary.md ({name}: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+           f"{'inplace' if (c['trajectory_ring'] == 1 or c['mode'] == 'step') else 'ring'}:{c['actions']}:{c['trajectory_layout']}"
+           + (f":{c['tune']}" if c.get("tune") else ""))
+    traffic[key] = {"bytes": b, "source": f"profiles/{ROUND}/rocprofv3_summary.md ({name}: separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
 print("\n```json")
 print(json.dumps(traffic, indent=1))
 print("```")

@@ -1,9 +1,10 @@
 #!/bin/bash
-# rocprofv3 evidence for one round: kernel trace + stats of the bench command, then separate PMC passes
-# (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they need 3 + 2).
-# Usage (via gpurun, from the repo root): bash tools/profile_round.sh r01
-TAG=${1:-r01}
-OUT=$PWD/gpurun_out/prof_$TAG
+# rocprofv3 evidence of one round: kernel trace + stats of the bench commands, then separate PMC passes
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they need 3 + 2; no --stats with --pmc).
+# Usage (via gpurun, from the repo root): bash tools/profile_round.sh <tag> [round]     e.g.  r03_p r03
+# Writes gpurun_out/<tag>/prof/{summary.md, traffic.json, trace_*, pmc_*}; tools/collect_profiles.sh copies the judged files.
+TAG=${1:-r03_p}; ROUND=${2:-r03}
+OUT=$PWD/gpurun_out/$TAG/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
@@ -13,21 +14,33 @@ run() {  # name, rocprof args..., -- cmd
   local name=$1; shift
   echo "== $name"
   timeout 600 rocprofv3 "$@" > $OUT/$name.log 2>&1
-  echo "rc=$? $(tail -1 $OUT/$name.log | cut -c1-300)"
+  echo "rc=$? $(grep '^{' $OUT/$name.log | tail -1 | cut -c1-160)"
 }
-# 1. kernel trace + stats of the exact default bench command (and of the step mode)
-run trace_rollout --kernel-trace --stats --output-format csv -d $OUT/trace_rollout -- $B
-run trace_step    --kernel-trace --stats --output-format csv -d $OUT/trace_step    -- $B --mode step --steps 2000 --warmup 50
-# 2. PMC passes: HBM-side bytes of the dominant kernel (per dispatch)
+# name | bench arguments
+CASES=(
+  "c2_ring|"
+  "c2_inplace|--in-place"
+  "c2_step|--mode step --steps 3000 --warmup 300"
+  "c2_step_lazy|--mode step --steps 3000 --warmup 300 --tune step_lazy=1"
+  "c3shard_ring|--envs-per-gpu 131072 --steps 1000 --warmup 100"
+  "c4_ring|--kind quad3d_sl --envs-per-gpu 262144 --steps 400 --warmup 50"
+)
+for c in "${CASES[@]}"; do
+  name=${c%%|*}; args=${c#*|}
+  [ -n "$ONLY" ] && [[ ! " $ONLY " =~ " $name " ]] && continue
+  run trace_$name --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- $B $args
+  for C in FETCH_SIZE WRITE_SIZE; do
+    # fewer launches under the counters; the warm-up still cycles the whole ring once
+    run pmc_${name}_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_${name}_$C -- $B $args --steps 60 --warmup 30
+  done
+done
+# calibration of the two counters on a known byte count far beyond the Infinity Cache (16 M envs, single step)
 for C in FETCH_SIZE WRITE_SIZE; do
-  run pmc_rollout_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_rollout_$C -- $B --steps 40 --warmup 20
-  run pmc_step_$C    --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_step_$C    -- $B --mode step --steps 40 --warmup 4
-  # calibration: same kernel, working set far beyond the 256 MiB Infinity Cache, known byte count
-  run pmc_calib_$C   --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_calib_$C   -- $B --mode step --envs-per-gpu 16777216 --steps 6 --warmup 2
+  run pmc_calib_$C --pmc $C --kernel-trace --output-format csv -d $OUT/pmc_calib_$C -- $B --mode step --envs-per-gpu 16777216 --steps 6 --warmup 2
 done
 cd $REPO
-python tools/parse_rocprof.py $OUT > $OUT/summary.md 2>&1
-tail -60 $OUT/summary.md
-# keep the merge small: drop raw per-dispatch traces beyond the stats/counter CSVs
+python tools/parse_rocprof.py $OUT $ROUND > $OUT/summary.md 2>&1
+tail -80 $OUT/summary.md
 find $OUT -name "*_agent_info.csv" -delete
+find $OUT -name "*kernel_trace.csv" -size +2M -delete
 du -sh $OUT
