@@ -240,7 +240,7 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
 // 1024-thread / 160 KiB-LDS limits).  So the rule is capacity, not a tuned constant: two wavefronts iff
 // N <= 16 384 x (pairs that fit one workgroup for this kind and action source).
 template <int K, bool DRAWS> constexpr int split_pairs_max() {
-    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * SplitTile<Dims<K>::NS, Dims<K>::NA, DRAWS>::WORDS_PER_PAIR));
+    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * split_words_per_pair<K, DRAWS ? ACT_RANDOM_SPLIT : ACT_CONTROLLER_SPLIT>()));
     constexpr int cap = split_group_cap<K, DRAWS>();   // threads / registers (rmav_kernels.hpp)
     return by_lds < cap ? by_lds : cap;
 }
@@ -278,7 +278,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     if constexpr (is_split(MODE)) {
         // (integrator, memory wavefront) pairs: as many per workgroup as make ONE workgroup per CU (256 workgroups),
         // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_TUNE_SPLIT_GROUP = 1..8 overrides.
-        using Tile = SplitTile<Dims<K>::NS, Dims<K>::NA, split_feeds_actions(MODE)>;
+        constexpr size_t lds_per_pair = sizeof(float) * split_words_per_pair<K, MODE>();
         const int forced = h->tune[RMAV_TUNE_SPLIT_GROUP];
         constexpr int g_max = split_pairs_max<K, split_feeds_actions(MODE)>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
@@ -290,7 +290,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * h->n < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
             a.flags |= F_LEAN;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
-                           sizeof(float) * Tile::WORDS_PER_PAIR * g, h->stream, a, p, pc);
+                           lds_per_pair * g, h->stream, a, p, pc);
     } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
         const int64_t per_wg = block_size(h) / 2;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds,
@@ -848,7 +848,7 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
     if (action_mode == RMAV_ACT_BUFFER && !actions_in)
         return fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
     if (ctrl_out && h->kind == RMAV_REINMAV)
-        return fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (RMAV_ACT_CONTROLLER); there is no separate control()");
+        return fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (the controller action mode); there is no separate control()");
     const size_t n = (size_t)h->n, T = (size_t)n_steps;
     const size_t nS = kStateDim[h->kind], nA = kActionDim[h->kind];
     const size_t b_act = T * nA * n * sizeof(float), b_obs = T * nS * n * sizeof(float);
@@ -1091,13 +1091,13 @@ int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem) {
 int rmav_get_time(rmav_handle h, double *out, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only RMAV_REINMAV envs carry their own clock");
+    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
     return copy_out(h, (const double *)h->env_time, out, (size_t)h->n, mem);
 }
 int rmav_set_time(rmav_handle h, const double *in, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only RMAV_REINMAV envs carry their own clock");
+    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
     return copy_in(h, h->env_time, in, (size_t)h->n, mem);
 }
 

@@ -88,12 +88,21 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
     static constexpr int ACT = DONE + 64;   // actions [c][lane], only when the integrator computes them
     static constexpr int O_ROW = ACT + (DRAWS ? 0 : NA * 64), O_HALF = CH * O_ROW, O_WORDS = 2 * O_HALF;
     static constexpr int WORDS = A_WORDS + O_WORDS;
-    // + the integrator's spare reset state [c][lane] (drawn once per launch, consumed by the first termination of a lane):
-    // in LDS rather than in NS vector registers that are live through the whole step loop - what the 128-register budget of
-    // 8 pairs per workgroup (1024 threads) was missing for the slung-load kinds.  Laid out after the tiles of all pairs.
+    // + (3-D slung load only, see spare_in_lds) the integrator's spare reset state [c][lane], drawn once per
+    // launch and consumed by the first termination of a lane, laid out after the tiles of all pairs
     static constexpr int SPARE = NS * 64;
-    static constexpr int WORDS_PER_PAIR = WORDS + SPARE;
 };
+// Where the integrator of a two-wavefront kernel keeps its spare reset state.  In registers it is a predicated copy when a
+// lane terminates; in LDS it frees NS = 16 registers of the step loop - what the controller-driven 3-D slung-load integrator
+// (fp64 controller on top of the fp64 step: 140 VGPRs with it, 124 without) needs to fit the 128-register budget of 8 pairs per
+// workgroup - but puts an LDS round trip into the reset path, which nearly every step of a 4-pair workgroup takes (one
+// barrier for all pairs; 97 % of its steps have a terminating lane somewhere): 2-D kinds at 65 536 envs +5 %.  So only there.
+// (The random- and caller-action 3-D slung-load integrators sit at 127-131 registers with it: LDS as well; measured equal.)
+template <int K, int MODE> constexpr bool spare_in_lds() { return K == QUAD3D_SL && is_split(MODE); }
+template <int K, int MODE> constexpr int split_words_per_pair() {
+    using T = SplitTile<Dims<K>::NS, Dims<K>::NA, split_feeds_actions(MODE)>;
+    return T::WORDS + (spare_in_lds<K, MODE>() ? T::SPARE : 0);
+}
 // F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
 // memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u };
@@ -701,12 +710,13 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         // is drawn ONCE up front (all lanes busy, amortised over the launch) and the in-loop reset
         // becomes a predicated register copy.  A second termination of the same env inside one launch
         // falls back to drawing on demand.  Same counters, same bits either way.
-        // (two-wavefront kernels keep it in LDS - SplitTile::SPARE - so that it does not occupy NS registers in the step loop)
-        [[maybe_unused]] float spare[SPLIT ? 1 : NS];
+        // (spare_in_lds<K, MODE>: one kernel keeps it in LDS instead, so that it does not occupy NS registers in the step loop)
+        constexpr bool SPARE_LDS = spare_in_lds<K, MODE>();
+        [[maybe_unused]] float spare[SPARE_LDS ? 1 : NS];
         [[maybe_unused]] float *lds_spare = nullptr;
         bool have_spare = false;
         if (K != REINMAV && auto_reset && a.n_steps >= 8) {   // ReinmavEnv.reset() is a no-op (reinmav_env.py:348-351)
-            if constexpr (SPLIT) {
+            if constexpr (SPARE_LDS) {
                 float sp[NS];
                 reset_state<K>(a.seed, env_id, rc, sp);
                 lds_spare = lds_w + split_g * SplitTile<NS, NA, DRAWS>::WORDS +
@@ -912,7 +922,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 if (have_spare) {
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
-                        if constexpr (SPLIT) s[c] = lds_spare[c * 64];
+                        if constexpr (SPARE_LDS) s[c] = lds_spare[c * 64];
                         else s[c] = spare[c];
                     }
                     have_spare = false;

@@ -1,13 +1,23 @@
 #!/bin/bash
-# copy the judged evidence of tools/gpu_r02_final.sh <tag> (gpurun_out/<tag>, gpurun_out/prof_r02c) into profiles/r02
-TAG=${1:-r02_final}; P=gpurun_out/prof_r02c; F=gpurun_out/$TAG; D=profiles/r02
-for c in c2_inplace c2_ring c2_step c3shard_ring c4_ring; do
-  f=$(find $P/trace_$c -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d' ' -f2); cp "$f" $D/trace_${c}_kernel_stats.csv
-done
-for c in c2_inplace c2_ring c2_step c3shard_ring c4_ring calib; do for C in FETCH_SIZE WRITE_SIZE; do
-  best=""; for g in $(find $P/pmc_${c}_$C -name "*counter_collection.csv"); do grep -q "k_rollout\|k_step" "$g" && best=$g; done
-  [ -n "$best" ] && { head -1 "$best"; grep "k_rollout\|k_step" "$best"; } > $D/pmc/pmc_${c}_$C.csv
-done; done
-cp $P/summary.md $D/rocprofv3_summary.md; cp $P/traffic.json profiles/traffic.json
-for f in bench_n1 bench_n1_k20 bench_c3shard bench_c4 bench_torchrun1_c3shard; do grep '^{' $F/$f.json > $D/$f.json.log; done
-cp $F/device.txt $D/device.txt
+# Copy the judged evidence of a GPU session into profiles/<round>/ (tracked).
+# Usage: bash tools/collect_profiles.sh <session tag> <round>      e.g.  r03_p r03
+# Expects gpurun_out/<tag>/prof/ from `gpu_session.sh <tag> prof` and, optionally, bench_*.json / device.txt / sweep*.md /
+# sq_counters.txt / step_latency.txt from the other stages of the same tag.
+TAG=${1:?session tag}; ROUND=${2:?round}; F=gpurun_out/$TAG; P=$F/prof; D=profiles/$ROUND
+mkdir -p $D/pmc
+if [ -d $P ]; then
+  for d in $P/trace_*; do
+    [ -d "$d" ] || continue; c=${d##*/trace_}
+    f=$(find $d -name "*kernel_stats.csv" -printf "%s %p\n" | sort -n | tail -1 | cut -d' ' -f2); [ -n "$f" ] && cp "$f" $D/trace_${c}_kernel_stats.csv
+  done
+  for d in $P/pmc_*; do
+    [ -d "$d" ] || continue; c=${d##*/}
+    best=""; for g in $(find $d -name "*counter_collection.csv"); do grep -q "k_rollout\|k_step" "$g" && best=$g; done
+    [ -n "$best" ] && { head -1 "$best"; grep "k_rollout\|k_step" "$best"; } > $D/pmc/$c.csv
+  done
+  cp $P/summary.md $D/rocprofv3_summary.md
+  cp $P/traffic.json profiles/traffic.json
+fi
+for f in $F/bench_*.json; do [ -f "$f" ] && grep '^{' $f > $D/$(basename $f).log; done
+for f in device.txt sweep.md sweep.jsonl sq_counters.txt step_latency.txt; do [ -f $F/$f ] && cp $F/$f $D/$f; done
+ls $D

@@ -11,6 +11,8 @@ mode, kind, actions = os.environ.get("MODE", "rollout"), os.environ.get("KIND", 
 secs = float(os.environ.get("SECS", "3"))
 dev = torch.device("cuda", 0)
 env = g.BatchedQuadrotor(kind, n, seed=0)
+if os.environ.get("TUNE"):   # e.g. TUNE=split=0,store_policy=2 (rmav_set_tuning overrides)
+    env.set_tuning(**{kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ["TUNE"].split(",")})
 nS, nA = env.nS, env.nA
 want = () if mode == "compute" else ("actions", "obs", "rew", "done")
 ring = [dict(actions=torch.zeros((T, nA, n), device=dev), obs=torch.zeros((T, nS, n), device=dev),
@@ -67,6 +69,6 @@ steady = [u for t, u in rows if t > secs / 2]
 burst = min(u for t, u in rows)
 sp = [(p, c, f, m) for t, p, c, f, m in samples if t - t_start > secs / 2]
 avg = lambda xs: sum(xs) / max(1, len(xs))
-print(f"{mode:8s} {kind} {actions} n={n} split={os.environ.get('RMAV_SPLIT', 'auto')} lib={os.path.basename(os.environ.get('RMAV_LIB_PATH', 'default'))}: "
+print(f"{mode:8s} {kind} {actions} n={n} tune={os.environ.get('TUNE', '')} lib={os.path.basename(os.environ.get('RMAV_LIB_PATH', 'default'))}: "
       f"best slice {burst:6.1f} us, steady {avg(steady):6.1f} us ({nbytes / avg(steady) / 1e6:.2f} TB/s), "
       f"power {avg([x[0] for x in sp]):5.0f} W, sclk {avg([x[1] for x in sp]):5.0f} (min {min([x[1] for x in sp] or [0]):.0f}) fclk {avg([x[2] for x in sp]):5.0f} mclk {avg([x[3] for x in sp]):5.0f} MHz, {len(sp)} samples [{bdf}]", flush=True)
