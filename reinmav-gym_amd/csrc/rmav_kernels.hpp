@@ -682,7 +682,8 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         // 1.3 %/step termination rate of random actions).
         int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
         uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
-        bool sb_dirty = false, rc_dirty = false;   // (flags, not copies of the loaded values: two registers less in the step loop)
+        // (written back unconditionally at the end of the launch: neither copies of the loaded values - two registers of the
+        // step loop - nor per-lane dirty masks - four scalar instructions per step - for 8 B per env and LAUNCH)
         const uint64_t env_id = a.env_base + (uint64_t)li;
         // per-env (domain-randomised) constants override the shared kernel arguments for this lane
         typename Env<K>::P pl = p_shared;
@@ -714,13 +715,14 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         constexpr bool SPARE_LDS = spare_in_lds<K, MODE>();
         [[maybe_unused]] float spare[SPARE_LDS ? 1 : NS];
         [[maybe_unused]] float *lds_spare = nullptr;
+        if constexpr (SPARE_LDS)
+            lds_spare = lds_w + split_g * SplitTile<NS, NA, DRAWS>::WORDS +
+                        (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * SplitTile<NS, NA, DRAWS>::SPARE + (threadIdx.x & 63u);
         bool have_spare = false;
         if (K != REINMAV && auto_reset && a.n_steps >= 8) {   // ReinmavEnv.reset() is a no-op (reinmav_env.py:348-351)
             if constexpr (SPARE_LDS) {
                 float sp[NS];
                 reset_state<K>(a.seed, env_id, rc, sp);
-                lds_spare = lds_w + split_g * SplitTile<NS, NA, DRAWS>::WORDS +
-                            (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * SplitTile<NS, NA, DRAWS>::SPARE + (threadIdx.x & 63u);
 #pragma unroll
                 for (int c = 0; c < NS; ++c) lds_spare[c * 64] = sp[c];   // read back by this lane only: no barrier needed
             } else {
@@ -884,7 +886,6 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 if (done) {
                     r = (sb < 0) ? 1.0f : 0.0f;
                     sb = (sb < 0) ? 0 : sb + 1;
-                    sb_dirty = true;
                 }
             }
             if (act_out) {
@@ -918,19 +919,31 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                     el = 0;
                 }
             }
-            if (K != REINMAV && done && auto_reset) {
-                if (have_spare) {
+            if (K != REINMAV && auto_reset) {
+                const bool rst = done;
+                // A lane that terminates again in the same launch has no spare left: draw one first.  Rare, and skipped with ONE
+                // wave-uniform branch; what remains on the common path is a single predicated copy (the nested form - copy the
+                // spare OR draw - cost a dozen exec-mask instructions per step).
+                if (__ballot(rst && !have_spare) != 0) {
+                    if (rst && !have_spare) {
+                        float sp[NS];
+                        reset_state<K>(a.seed, env_id, rc, sp);
+#pragma unroll
+                        for (int c = 0; c < NS; ++c) {
+                            if constexpr (SPARE_LDS) lds_spare[c * 64] = sp[c];
+                            else spare[c] = sp[c];
+                        }
+                    }
+                }
+                if (rst) {
 #pragma unroll
                     for (int c = 0; c < NS; ++c) {
                         if constexpr (SPARE_LDS) s[c] = lds_spare[c * 64];
                         else s[c] = spare[c];
                     }
                     have_spare = false;
-                } else {
-                    reset_state<K>(a.seed, env_id, rc, s);
+                    rc += 1;
                 }
-                rc += 1;
-                rc_dirty = true;
             }
             if constexpr (SPLIT) {
                 // hand obs / reward / done (and the controller's action) to the memory wavefront; it drains this
@@ -1029,8 +1042,8 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
         }
         if constexpr (K == REINMAV) a.env_time[li] = tenv;
-        if (sb_dirty) buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-        if (rc_dirty) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
+        buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
+        buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     }
 
     if (track) {
