@@ -282,7 +282,16 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         const int forced = h->tune[RMAV_TUNE_SPLIT_GROUP];
         constexpr int g_max = split_pairs_max<K, split_feeds_actions(MODE)>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
-        int g = (forced >= 1 && forced <= g_max) ? forced : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
+        // Round 3 (profiles/r03/pairs_per_workgroup.md): one s_barrier synchronises ALL pairs of a workgroup, so every pair
+        // pays for the slowest one's reset path each step.  Where the step time is the integrator's latency (the 2-D kinds,
+        // whose steps move half the bytes, and every controller-driven rollout: fp64 controller in the integrator) rather than
+        // the store stream, ONE pair per workgroup is faster: 65 536 envs quadrotor2d-slungload 47.2 -> 43.1 us per 64-step launch,
+        // controller-driven quadrotor3d 56.7 -> 52.3.  The store-bound combinations (3-D kinds with random / caller actions) keep
+        // one workgroup per CU (adjacent pairs store adjacent 256-byte segments: 65 536 envs quadrotor3d 41.6 vs 50.7 us), and so
+        // do the others at 131 072 envs, where two pairs share every SIMD anyway (quadrotor2d excepted: 51.6 vs 54.5).
+        constexpr bool latency_bound = (K == QUAD2D || K == QUAD2D_SL) || MODE == ACT_CONTROLLER_SPLIT;
+        const bool one_pair = latency_bound && (count <= 98304 || K == QUAD2D);
+        int g = (forced >= 1 && forced <= g_max) ? forced : one_pair ? 1 : (int)((count + kEnvsPerCuSlot - 1) / kEnvsPerCuSlot);
         if (g < 1) g = 1;
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;

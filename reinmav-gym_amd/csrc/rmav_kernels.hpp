@@ -11,7 +11,8 @@
 //   env_time   f64 [N]       RMAV_REINMAV only: each env's clock
 //   pe[3]      f32 [N]       optional per-env mass / load mass / tether length (domain randomisation)
 // Caller buffers: actions [T][nA][N] | [T][N][nA], obs [T][nS][N] | [T][N][nS], rew f32 [T][N],
-// done u8 [T][N].
+// done u8 [T][N].  INVARIANT: every kernel stores exactly 0 or 1 into `done` (all done stores below are `cond ? 1 : 0`):
+// the Python layer views the bytes as bool without a conversion pass (vec_env.py).
 //
 // One kernel template covers step (n_steps = 1) and the fused rollout (n_steps = T, state held in
 // registers between steps, so per-step HBM traffic shrinks to actions-in + trajectory-out).  The action

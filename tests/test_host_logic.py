@@ -58,20 +58,6 @@ def test_trajectory_schema_roundtrip(tmp_path, golden):
     assert g["state"].shape == (400, 4, 10) and g["done"].shape == (400, 4)
 
 
-def test_run_cli_argument_parsing():
-    """gym_reinmav_amd.run keeps baselines' command line: known flags + free-form --k=v learn kwargs
-    (gym_reinmav/run.py:151-172), parsed without eval()."""
-    from gym_reinmav_amd.run import arg_parser, parse_unknown
-
-    args, unknown = arg_parser().parse_known_args(["--alg=ppo2", "--env=quadrotor3d-v0", "--network=mlp", "--num_env", "8",
-                                                   "--num_timesteps=2e5", "--play", "--nsteps=16", "--lr", "1e-3",
-                                                   "--cliprange=0.1", "--load_path=/tmp/x.pt", "--env_type", "native"])
-    assert args.alg == "ppo2" and args.env == "quadrotor3d-v0" and args.num_env == 8 and args.play and args.num_timesteps == 2e5
-    kw = parse_unknown(unknown)
-    assert kw == {"nsteps": 16, "lr": 1e-3, "cliprange": 0.1, "load_path": "/tmp/x.pt"}
-    assert parse_unknown(["--x=__import__('os').system('true')"]) == {"x": "__import__('os').system('true')"}   # not evaluated
-
-
 def test_bench_byte_accounting():
     """bench.py's roofline bytes for the fused rollout: trajectory out per env-step + state / bookkeeping per launch."""
     import importlib.util
