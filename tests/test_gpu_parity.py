@@ -218,6 +218,7 @@ def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
     for name, tune in (("default", {}), ("one wavefront", {"split": 0, "slice": 0}),
                        ("two wavefronts, one launch", {"split": 1, "slice": 0}),
                        ("two wavefronts, sliced", {"slice": 1}),
+                       ("two wavefronts, generic drain, 3 pairs per workgroup", {"split": 1, "slice": 0, "lean": 0, "split_group": 3}),
                        ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0})):
         env = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
@@ -233,6 +234,36 @@ def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
             h.update(np.ascontiguousarray(eb[k]).tobytes())
         t = env.episode_totals()
         digests[name] = (h.hexdigest(), t["episodes"], t["length_sum"])
+        env.close()
+    assert len(set(digests.values())) == 1, digests
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_single_step_variants_give_the_same_bits(G, kind):
+    """rmav_step through k_step (default), k_step with lane-predicated counter loads (RMAV_TUNE_STEP_LAZY) and the rollout
+    kernel at n_steps = 1 (RMAV_TUNE_STEP_KERNEL = 0): same outputs, state, counters and episode statistics, bit for bit,
+    over 60 steps with ~1 % of the lanes terminating per step (ragged batch: the last wavefront has clones)."""
+    import hashlib
+
+    n = 4099
+    lo, hi = BOX[kind]
+    acts = np.random.RandomState(3).uniform(lo, hi, (60, n, NA[kind])).astype(np.float32)
+    digests = {}
+    for name, tune in (("k_step", {}), ("lazy", {"step_lazy": 1}), ("rollout kernel", {"step_kernel": 0})):
+        env = G.BatchedQuadrotor(kind, n, seed=8, auto_reset=True, track_episodes=True)
+        env.set_tuning(**tune)
+        h = hashlib.sha256()
+        for k in range(60):
+            for x in env.step(acts[k]):
+                h.update(np.ascontiguousarray(x).tobytes())
+        for x in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
+            h.update(np.ascontiguousarray(x).tobytes())
+        eb = env.episode_buffers()
+        for key in sorted(eb):
+            h.update(np.ascontiguousarray(eb[key]).tobytes())
+        t = env.episode_totals()
+        digests[name] = (h.hexdigest(), t["episodes"], t["length_sum"])
+        assert t["episodes"] > 0
         env.close()
     assert len(set(digests.values())) == 1, digests
 
