@@ -200,7 +200,9 @@ enum rmav_tuning_key {
     RMAV_TUNE_SPLIT_MIN_STEPS = 6, /* shortest fused launch that may use the two-wavefront kernel (default 2) */
     RMAV_TUNE_LEAN = 7,            /* 0: the two-wavefront kernel's memory wavefront uses the generic (pointer-advancing) drain */
     RMAV_TUNE_STEP_LAZY = 8,       /* 1: k_step loads steps_beyond_done / reset counters only in lanes whose env terminates */
-    RMAV_TUNE_COUNT = 9
+    RMAV_TUNE_SLICE_ENVS = 9,      /* E >= 64: fused rollouts as two-wavefront launches over slices of at most E envs */
+    RMAV_TUNE_HOST_FLAG = 10,      /* 0: host-pointer single-wavefront steps wait with hipStreamSynchronize instead of the pinned completion word */
+    RMAV_TUNE_COUNT = 11
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);

@@ -80,6 +80,9 @@ struct rmav_env_s {
     void *pinned;
     void *pinned_dev;
     size_t pinned_bytes;
+    // completion word of single-wavefront k_step launches through the pinned block (RolloutArgs::done_flag)
+    uint32_t *done_flag, *done_flag_dev;
+    uint32_t done_seq;
     // statistics exchange armed for the next fused rollout launch (rmav_allgather_stats_arm): where that launch's wavefronts
     // snapshot their envs' statistics and publish their arrival; `fired` once a launch has taken it
     struct {
@@ -322,6 +325,11 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, boo
     if (a.n_steps < min_steps || h->kind > RMAV_QUAD3D_SL) return false;
     const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
     if (forced == 0) return false;
+    // RMAV_TUNE_SLICE_ENVS = E (a multiple of 64): the two-wavefront kernel in launches of at most E envs each (measurement knob)
+    if (const int64_t e = h->tune[RMAV_TUNE_SLICE_ENVS]; e >= 64 && e < h->n && h->n <= 8 * e) {
+        *slices = (int)((h->n + e - 1) / e);
+        return true;
+    }
     if (h->n <= cap) return true;
     // Two rounds of the two-wavefront kernel - two launches over balanced halves of the env range - beat one launch of the
     // one-wavefront kernel for the slung-load kinds (fp64 integrator: the one-wavefront kernel holds only 3-4 of them per SIMD)
@@ -523,6 +531,7 @@ void free_all(rmav_handle h) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->done_flag) (void)hipHostFree(h->done_flag);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     h->magic = 0;
     delete h;
@@ -905,6 +914,25 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
     if (layout == RMAV_AOS) a.flags |= F_AOS;
     a.ctrl_out = d_ctrl;
     const int kmode = d_ctrl ? (int)ACT_BUFFER_CTRL : action_mode;
+    // One wavefront, one k_step launch, outputs in the pinned block: the kernel publishes its completion in a pinned word and
+    // the host spins on that (bounded) instead of hipStreamSynchronize.  What the gym-shaped single env runs.
+    bool flag_wait = false;
+    if (pinned && n_steps == 1 && h->n <= 64 && action_mode == RMAV_ACT_BUFFER && h->kind != RMAV_REINMAV &&
+        h->tune[RMAV_TUNE_STEP_KERNEL] != 0 && h->tune[RMAV_TUNE_HOST_FLAG] != 0) {
+        if (!h->done_flag && hipHostMalloc((void **)&h->done_flag, 64, hipHostMallocMapped) == hipSuccess) {
+            *h->done_flag = 0;
+            if (hipHostGetDevicePointer((void **)&h->done_flag_dev, h->done_flag, 0) != hipSuccess) {
+                (void)hipHostFree(h->done_flag);
+                h->done_flag = nullptr;
+            }
+        }
+        (void)hipGetLastError();
+        if (h->done_flag) {
+            a.done_flag = h->done_flag_dev;
+            a.done_seq = ++h->done_seq;
+            flag_wait = true;
+        }
+    }
     h->xchg.allow = fused != 0;   // one fused launch may carry an armed exchange's snapshot; the fused = 0 loop may not
     if (fused) {
         a.n_steps = n_steps;
@@ -930,7 +958,21 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
 
     if (mem == RMAV_HOST) {
         if (pinned) {
-            HIP_TRY(hipStreamSynchronize(h->stream));
+            bool seen = false;
+            if (flag_wait) {   // ~10 us is the whole launch; 2 ms covers a cold first launch, then fall back to the stream
+                timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                const volatile uint32_t *f = h->done_flag;
+                for (uint32_t spin = 0;; ++spin) {
+                    if (*f == h->done_seq) { seen = true; break; }
+                    if ((spin & 255u) == 255u) {
+                        clock_gettime(CLOCK_MONOTONIC, &t1);
+                        if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 2000000ll) break;
+                    }
+                }
+                __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            }
+            if (!seen) HIP_TRY(hipStreamSynchronize(h->stream));
             if (want_aout) memcpy(actions_out, hbase + o_aout, b_act);
             if (obs_out) memcpy(obs_out, hbase + o_obs, b_obs);
             if (rew_out) memcpy(rew_out, hbase + o_rew, b_rew);

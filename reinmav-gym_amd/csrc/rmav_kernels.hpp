@@ -154,6 +154,12 @@ struct RolloutArgs {
     int64_t xcmax;
     uint32_t *xarrive;
     uint32_t xseq;
+    // k_step of a batch that fits ONE wavefront, outputs in the handle's pinned host block: the wavefront ends by publishing
+    // done_seq in this pinned word (system-scope release), and the host spins on it instead of going through
+    // hipStreamSynchronize (the kernel's end-of-kernel release + the completion signal + the runtime's wait: ~4 us of a
+    // ~15 us host round trip).  nullptr otherwise.
+    uint32_t *done_flag;
+    uint32_t done_seq;
 };
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
@@ -1300,6 +1306,10 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
                 slot->length_sum = tot.length_sum + len;
             }
         }
+    }
+    if (a.done_flag) {   // wave-uniform; the launch is a single wavefront (the host guarantees it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane's output stores have been acknowledged
+        if (gi == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
