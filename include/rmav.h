@@ -46,7 +46,8 @@
  *     one GPU and one HIP stream; it is NOT thread-safe; distinct handles are independent.
  *   - `mem` says where every caller-supplied pointer of that call lives: RMAV_HOST (the library
  *     stages - calls that move <= 256 KiB go zero-copy through a pinned, device-mapped block owned by the
- *     handle: one launch + one synchronise, which is what the gym-shaped single env uses; bulk calls go
+ *     handle: one launch + one synchronise (single-step calls of <= 64 envs wait on a pinned completion word the kernel
+ *     writes instead), which is what the gym-shaped single env uses; bulk calls go
  *     through device scratch - and synchronises before returning) or RMAV_DEVICE (HIP device
  *     pointers, e.g. torch tensor data_ptr(); work is enqueued on the handle's stream and the call
  *     returns without synchronising).
