@@ -1183,9 +1183,21 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
 #pragma unroll
     for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
     if (aos) {
+        // batch-major actions [N][nA] (what a policy network / the VecEnv hands over): ONE 8- / 16-byte load per lane when the
+        // buffer is aligned for it (torch tensors are), instead of nA dword loads that each touch all of the wavefront's lines
         const float *src = a.act_in + (int64_t)li * NA;
+        if ((reinterpret_cast<uintptr_t>(a.act_in) & (NA * 4 - 1)) == 0) {   // wave-uniform (NA is 2 or 4)
+            if constexpr (NA == 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                act[0] = v.x; act[1] = v.y; act[2] = v.z; act[3] = v.w;
+            } else {
+                const float2 v = *reinterpret_cast<const float2 *>(src);
+                act[0] = v.x; act[1] = v.y;
+            }
+        } else {
 #pragma unroll
-        for (int c = 0; c < NA; ++c) act[c] = src[c];
+            for (int c = 0; c < NA; ++c) act[c] = src[c];
+        }
     } else {
         const rsrc_t r = make_rsrc(a.act_in);
 #pragma unroll
@@ -1260,16 +1272,18 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     if (valid) {
 #pragma unroll
         for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
-        if (a.obs_out) {
-            if (aos) {
-                float *dst = a.obs_out + (int64_t)li * NS;
+    }
+    // (Batch-major obs through an LDS transpose - as the fused kernels do for big launches - was built and measured here in
+    // round 3: QuadrotorVecEnv.step at 65 536 envs 4.91-5.02 us with it, 4.99-5.01 without; not kept.)
+    if (valid && a.obs_out) {
+        if (aos) {
+            float *dst = a.obs_out + (int64_t)li * NS;
 #pragma unroll
-                for (int c = 0; c < NS; ++c) dst[c] = s[c];
-            } else {
-                const rsrc_t ro = make_rsrc(a.obs_out);
+            for (int c = 0; c < NS; ++c) dst[c] = s[c];
+        } else {
+            const rsrc_t ro = make_rsrc(a.obs_out);
 #pragma unroll
-                for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
-            }
+            for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
         }
     }
     if constexpr (CTRL) {   // control() of the state this launch leaves behind
