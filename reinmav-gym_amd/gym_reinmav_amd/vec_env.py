@@ -32,7 +32,7 @@ ENV_IDS = {
     "quadrotor3d-slungload-v0": "quad3d_sl",
 }
 _ACTION_BOX = {"reinmav": (0.0, 3.5316), "quad2d": (-10.0, 10.0), "quad2d_sl": (-10.0, 10.0), "quad3d": (0.0, 10.0), "quad3d_sl": (-10.0, 10.0)}
-_BLOCK = 16   # steps of fresh output tensors allocated at a time (one allocation each for obs / rew / done)
+_BLOCK = 16   # steps of fresh output tensors allocated at a time (one allocation each for obs / rew / done; 64 measured the same)
 
 
 class QuadrotorVecEnv:
