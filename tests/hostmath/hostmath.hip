@@ -99,6 +99,7 @@ int hm_reset_state(int kind, uint64_t seed, uint64_t env, uint32_t idx, float *s
     }
     return 0;
 }
+double hm_fast_atan2(double y, double x) { return fast_atan2(y, x); }   // the 2-D controller's atan2 (host form: true division)
 int hm_random_action(int kind, uint64_t seed, uint64_t env, uint64_t t, float lo, float hi, float *a) {
     switch (kind) {
     case QUAD2D: action_k<QUAD2D>(seed, env, t, lo, hi, a); break;

@@ -80,8 +80,29 @@ def test_rng_streams_bit_exact(hm, kind):
             s = np.zeros(NS[kind], np.float32)
             hm.hm_reset_state(k, C.c_uint64(9), C.c_uint64(env), C.c_uint32(idx), s.ctypes.data_as(FP))
             assert np.array_equal(s, O.reset_state(kind, 9, env, idx))
-        for t in (0, 5, 2**33 + 1):
+        for t in (0, 4, 5, 2**33 + 1, 2**33 + 2):
             a = np.zeros(NA[kind], np.float32)
             hm.hm_random_action(k, C.c_uint64(9), C.c_uint64(env), C.c_uint64(t), C.c_float(-10), C.c_float(10),
                                 a.ctypes.data_as(FP))
             assert np.array_equal(a, O.random_action(kind, 9, env, t, -10.0, 10.0))
+
+
+def test_fast_atan2_vs_libm(hm):
+    """The 2-D controller's atan2 (one reciprocal + an 8-coefficient polynomial, csrc/rmav_math.hpp): absolute error
+    <= 1e-12 against libm over the plane, the axes, the octant boundaries and tiny / huge magnitudes (1e-11 would do:
+    the result is multiplied by 1 / tau = 10 and rounded to fp32)."""
+    import math
+
+    hm.hm_fast_atan2.restype = C.c_double
+    hm.hm_fast_atan2.argtypes = [C.c_double, C.c_double]
+    rng = np.random.RandomState(0)
+    pts = [(y, x) for y, x in rng.uniform(-60, 60, (200000, 2))]
+    pts += [(y * 10.0 ** e, x * 10.0 ** e) for (y, x), e in zip(rng.uniform(-1, 1, (2000, 2)), rng.randint(-12, 12, 2000))]
+    t8 = math.tan(math.pi / 8)
+    for s1 in (-1.0, 1.0):
+        for s2 in (-1.0, 1.0):
+            pts += [(0.0, s2), (s1, 0.0), (s1, s2), (s1 * t8, s2), (s1, s2 * t8), (s1 * (t8 + 1e-15), s2), (s1 * 1e-300, s2),
+                    (s1 * 3.0, s2 * 3.0000000001)]
+    pts.append((0.0, 0.0))
+    worst = max(abs(hm.hm_fast_atan2(y, x) - math.atan2(y, x)) for y, x in pts)
+    assert worst <= 1e-12, worst
