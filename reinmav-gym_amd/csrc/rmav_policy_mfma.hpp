@@ -71,6 +71,9 @@ __device__ __forceinline__ bf16x8_t ld_frag(const float *base, uint32_t lane) {
 // by k before it is rounded to bf16 and layer 2 receives k tanh() (the same fma with constants (-2k, k)), while the
 // biases of both layers are scaled once when the weights are staged into LDS (kTanhScale, scale_biases_for_tanh).
 // Saturates cleanly (2^zk = inf -> 1, 0 -> -1); absolute error ~1e-7, far below the bf16 rounding of the result.
+// (A transcendental-free form - clamp + odd 6-term polynomial on packed FMAs - measured 9.7 against 12.0 G env-steps/s in round
+// 3 and 3 % faster with 7 terms in round 2's slower kernel: v_exp / v_rcp cost this kernel no more than any other instruction,
+// the instruction COUNT is what it is bound by.)
 constexpr float kTanhScale = 2.8853900817779268f;   // 2 log2(e)
 
 // registers [8 half .. 8 half + 8) of an accumulator holding k z -> (A tanh(z) ... ) as a bf16 B fragment:
@@ -86,9 +89,15 @@ __device__ __forceinline__ bf16x8_t act_frag(const f32x16_t &acc, int half) {
     u32x4_t packed;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        f32x2_t v;
-        v[0] = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + 2 * j])), A, B);
-        v[1] = __builtin_fmaf(__builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(acc[8 * half + 2 * j + 1])), A, B);
+        // 1 + 2^zk and the final fma on value PAIRS (v_pk_add_f32 / v_pk_fma_f32: one instruction per two activations)
+        f32x2_t e;
+        e[0] = __builtin_amdgcn_exp2f(acc[8 * half + 2 * j]);
+        e[1] = __builtin_amdgcn_exp2f(acc[8 * half + 2 * j + 1]);
+        e = e + 1.0f;
+        f32x2_t rc;
+        rc[0] = __builtin_amdgcn_rcpf(e[0]);
+        rc[1] = __builtin_amdgcn_rcpf(e[1]);
+        const f32x2_t v = __builtin_elementwise_fma(rc, (f32x2_t){A, A}, (f32x2_t){B, B});
         packed[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
     }
     return __builtin_bit_cast(bf16x8_t, packed);
