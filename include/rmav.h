@@ -30,7 +30,7 @@
  *                                   test/test_quadrotor3d.py:16-22
  *   baselines VecEnv rollouts driven by gym_reinmav/run.py:89,190-211
  *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM)
- *   baselines ppo2 Runner.run(): model.step(obs) + env.step(a)    rmav_rollout_policy
+ *   baselines ppo2 Runner.run(): model.step(obs) + env.step(a)    rmav_rollout_policy (+ rmav_pack_policy)
  *   baselines Monitor episode statistics (info['episode'])        rmav_episode_totals / _buffers
  *   baselines ppo2 Runner.run() advantage pass (GAE lambda)       rmav_gae, rmav_normalize
  *   MPI rank probe / data-parallel workers gym_reinmav/run.py:18-21,177-182
@@ -278,6 +278,15 @@ int64_t rmav_policy_weight_count_bf16(void);
  * then logstd [4];  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h  (csrc/rmav_policy_mfma32.hpp explains why;
  * gym_reinmav_amd.ppo.pack_policy_weights_f32_mfma builds it). */
 int64_t rmav_policy_weight_count_f32_mfma(void);
+/* Builds such a weight buffer on the device in ONE launch on the handle's stream: with `flat` = the concatenation of the
+ * n_params (<= 16) parameter tensors `params[k]` (DEVICE pointers in a HOST array; sizes[k] elements each) followed by zeros,
+ * weights_out[i] = flat[idx_lo[i]] when idx_hi[i] < 0, else the two bf16 roundings of flat[idx_lo[i]] (low half) and
+ * flat[idx_hi[i]] (high half) in one 32-bit word.  idx_lo / idx_hi: int32 [n_out] on the DEVICE - the fixed permutation of a
+ * layout above (gym_reinmav_amd.ppo._PolicyPacker builds them once).  Replaces the chain of small tensor operations a
+ * learner would otherwise run before every rollout (baselines: model.step reads the live variables; here the actor's copy
+ * is re-derived from the learner's parameters). */
+int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                     const int32_t *idx_hi, int64_t n_out, float *weights_out);
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision);

@@ -1029,6 +1029,28 @@ int64_t rmav_policy_weight_count(int kind) {
 int64_t rmav_policy_weight_count_bf16(void) { return MfmaLayout::TOTAL; }
 int64_t rmav_policy_weight_count_f32_mfma(void) { return Mfma32Layout::TOTAL; }
 
+int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                     const int32_t *idx_hi, int64_t n_out, float *weights_out) {
+    CHECK_HANDLE(h);
+    if (n_params <= 0 || n_params > kPackMaxParams) return fail(RMAV_ERR_INVALID, "n_params must be in [1, %d]", kPackMaxParams);
+    if (!params || !sizes || !idx_lo || !idx_hi || !weights_out || n_out <= 0)
+        return fail(RMAV_ERR_INVALID, "params, sizes, idx_lo, idx_hi, weights_out are required and n_out > 0");
+    PackSrc src;
+    memset(&src, 0, sizeof(src));
+    int64_t end = 0;
+    for (int k = 0; k < n_params; ++k) {
+        if (!params[k] || sizes[k] < 0) return fail(RMAV_ERR_INVALID, "parameter %d is NULL or has a negative size", k);
+        end += sizes[k];
+        if (end > 0x7fffffff) return fail(RMAV_ERR_INVALID, "too many parameter elements");
+        src.p[k] = params[k];
+        src.end[k] = (int32_t)end;
+    }
+    src.n = n_params;
+    hipLaunchKernelGGL(k_pack_policy, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, src, idx_lo, idx_hi, n_out, weights_out);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision) {

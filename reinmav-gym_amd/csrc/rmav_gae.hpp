@@ -130,6 +130,42 @@ __global__ __launch_bounds__(256) void k_affine(float *__restrict__ x, int64_t c
     for (int64_t q = (n4 << 2) + tid; q < count; q += stride) x[q] = (x[q] - mean) * rstd;
 }
 
+// ---- policy weights -> the buffer rmav_rollout_policy reads ---------------------------------------------------
+// out word i = flat[lo[i]]  (hi[i] < 0), or the bf16 pair (flat[lo[i]], flat[hi[i]]) in one word (low half first), where `flat`
+// is the concatenation of the caller's parameter tensors (<= kPackMaxParams of them) followed by zeros.  The layouts of
+// include/rmav.h are fixed permutations + zero padding (+ bf16 rounding) of the parameters, so one gather launch replaces
+// the ~8 dependent torch launches (cat, index, convert, cat, copy: ~35 us) a repack used to cost before every rollout.
+constexpr int kPackMaxParams = 16;
+struct PackSrc {
+    const float *p[kPackMaxParams];
+    int32_t end[kPackMaxParams];   // exclusive prefix ends of the parameters inside `flat`
+    int32_t n;
+};
+__device__ __forceinline__ float pack_fetch(const PackSrc &src, int32_t j) {
+    int32_t begin = 0;
+#pragma unroll
+    for (int k = 0; k < kPackMaxParams; ++k) {
+        if (k < src.n && j >= begin && j < src.end[k]) return src.p[k][j - begin];
+        if (k < src.n) begin = src.end[k];
+    }
+    return 0.0f;   // the appended zero (padding)
+}
+__global__ __launch_bounds__(256) void k_pack_policy(const PackSrc src, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
+                                                     int64_t n_out, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const float a = pack_fetch(src, lo[i]);
+    const int32_t h = hi[i];
+    if (h < 0) {
+        out[i] = a;
+    } else {
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const f32x2_t v = {a, pack_fetch(src, h)};
+        out[i] = __builtin_bit_cast(float, __builtin_convertvector(v, bf16x2_t));   // round to nearest even, as torch's .to(bfloat16)
+    }
+}
+
 // ---- episode statistics exchange (the path's one collective) ------------------------------------------------
 // send = [2][cmax] int32: returns (bit pattern) then lengths of this rank's `count` envs, zero padded to cmax
 __global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ last_ret, const int32_t *__restrict__ last_len,

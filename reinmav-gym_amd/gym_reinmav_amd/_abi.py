@@ -95,6 +95,7 @@ PROTOTYPES = {
     "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
     "rmav_policy_weight_count_bf16": (C.c_int64, []),
     "rmav_policy_weight_count_f32_mfma": (C.c_int64, []),
+    "rmav_pack_policy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _vp, _vp, C.c_int64, _fp]),
     "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp, C.c_int]),
     "rmav_gae": (C.c_int, [C.c_void_p, C.c_int32, _fp, _u8p, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _vp]),
     "rmav_normalize": (C.c_int, [C.c_void_p, _fp, C.c_int64, C.c_float, C.c_float]),

@@ -270,6 +270,40 @@ class _PolicyPacker:
             self.n_bias = len(f32[0])
             self.n_out = 2 * (self.n_frag + self.n_bias) + 4
 
+    def native_maps(self):
+        """(idx_lo, idx_hi) int32 device tensors of ``rmav_pack_policy``: output word i = flat[idx_lo[i]] (idx_hi[i] < 0) or the
+        bf16 pair (flat[idx_lo[i]], flat[idx_hi[i]]); built once from the same index lists ``pack`` uses."""
+        if getattr(self, "_native", None) is None:
+            dev = self.params[0].device
+            if self.f32m or not self.bf16:
+                lo = self.idx_f32.to(torch.int32)
+                hi = torch.full_like(lo, -1)
+            else:
+                fr, bi, nf, nb = self.idx_frag.to(torch.int32), self.idx_bias.to(torch.int32), self.n_frag, self.n_bias
+                neg = lambda k: torch.full((k,), -1, dtype=torch.int32, device=dev)  # noqa: E731
+                # pack(): [fragments net 0 | biases net 0 | fragments net 1 | biases net 1 | logstd]; a fragment word = bf16 pair
+                lo = torch.cat([fr[0:2 * nf:2], bi[:nb], fr[2 * nf::2], bi[nb:2 * nb], bi[2 * nb:]])
+                hi = torch.cat([fr[1:2 * nf:2], neg(nb), fr[2 * nf + 1::2], neg(nb), neg(bi.numel() - 2 * nb)])
+            assert lo.numel() == self.n_out == hi.numel()
+            self._native = (lo.contiguous(), hi.contiguous())
+        return self._native
+
+    def pack_native(self, env, out: torch.Tensor) -> torch.Tensor:
+        """The same buffer as ``pack`` in ONE launch on the env's stream (``rmav_pack_policy``)."""
+        import ctypes as C
+
+        from . import _abi as A
+
+        lo, hi = self.native_maps()
+        ps = [p.detach() for p in self.params]
+        assert all(p.is_contiguous() and p.dtype == torch.float32 and p.is_cuda for p in ps), "parameters must be contiguous fp32 CUDA tensors"
+        n = len(ps)
+        ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in ps])
+        sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
+        A.check(A.lib().rmav_pack_policy(env._h, n, ptrs, sizes, C.c_void_p(lo.data_ptr()), C.c_void_p(hi.data_ptr()), self.n_out,
+                                         C.c_void_p(out.data_ptr())))
+        return out
+
     def pack(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in self.params] + [torch.zeros(1, device=self.params[0].device)])
@@ -309,7 +343,7 @@ class FusedPolicyCollector:
     that owns the env (``rmav_rollout_policy``), so nothing but the trajectory touches HBM."""
 
     def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, bf16_mfma: bool = False,
-                 f32_mfma: Optional[bool] = None):
+                 f32_mfma: Optional[bool] = None, native_pack: bool = True):
         """Actor arithmetic: fp32 on the fp32-input matrix instructions (``v_mfma_f32_32x32x2_f32``; the default),
         ``f32_mfma=False`` fp32 FMAs on the vector ALU (same precision class - only the summation order differs - at
         half the speed), ``bf16_mfma=True`` bf16 operands on the matrix cores (2.5x faster again, ~1e-2 on means)."""
@@ -340,14 +374,25 @@ class FusedPolicyCollector:
         self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma, f32_mfma=self.f32_mfma)
         assert self._packer.n_out == n_w, (self._packer.n_out, n_w)
         self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
+        # The weight repack before every rollout: one gather launch behind the C ABI (rmav_pack_policy).  As ~8 dependent torch
+        # launches (cat, gather, bf16 conversion, cat, copy) it cost ~38 us of a 0.21 ms rollout at 65 536 envs x 32 steps; a
+        # hipGraph of those launches replayed no faster (the dependent-launch floor, not the host, is what they cost).
+        self.native_pack = bool(native_pack)
+        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+        self._call = (A.lib().rmav_rollout_policy, env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]), p(self.rew), p(self.done),
+                      p(self.logp), p(self.val),
+                      A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32)
+
+    def _pack(self):
+        if self.native_pack:
+            self._packer.pack_native(self.env, self.weights)
+        else:
+            self._packer.pack(out=self.weights)
 
     def collect(self):
-        C, A = self._C, self._A
-        self._packer.pack(out=self.weights)
-        p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        A.check(A.lib().rmav_rollout_policy(self.env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]),
-                                            p(self.rew), p(self.done), p(self.logp), p(self.val),
-                                            A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32))
+        self._pack()
+        fn = self._call[0]
+        self._A.check(fn(*self._call[1:]))
         return self
 
     def roll_over(self):

@@ -204,6 +204,35 @@ def test_fused_policy_learner_loop(G):
     env.close()
 
 
+@pytest.mark.parametrize("kind", ["quad2d", "quad2d_sl", "quad3d", "quad3d_sl", "reinmav"])
+def test_native_weight_pack_equals_the_torch_pack(G, kind):
+    """rmav_pack_policy (one gather launch) writes bit for bit what the torch chain of _PolicyPacker.pack writes, for the three
+    weight layouts (fp32 VALU, fp32-input MFMA, bf16 MFMA fragments incl. the round-to-nearest-even bf16 conversion), and
+    follows in-place parameter updates."""
+    import torch
+    from gym_reinmav_amd.ppo import MlpPolicy, _PolicyPacker
+
+    torch.manual_seed(11)
+    env = G.BatchedQuadrotor(kind, 64, seed=1)
+    pol = MlpPolicy(env.nS, env.nA, init_logstd=-0.7).cuda()
+    with torch.no_grad():
+        for prm in pol.parameters():
+            prm.add_(torch.randn_like(prm) * 0.3)
+    for bf16, f32m in ((False, False), (False, True), (True, False)):
+        pk = _PolicyPacker(pol, env.nS, bf16, f32_mfma=f32m)
+        for rnd in range(2):
+            ref = pk.pack()
+            out = torch.full_like(ref, float("nan"))
+            pk.pack_native(env, out)
+            env.sync()
+            torch.cuda.synchronize()
+            assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (bf16, f32m, rnd)
+            with torch.no_grad():                       # an optimiser step updates in place: the next pack must see it
+                for prm in pol.parameters():
+                    prm.mul_(1.01).add_(0.003)
+    env.close()
+
+
 @pytest.mark.parametrize("kind,n", [("quad3d", 512), ("quad3d_sl", 300), ("quad2d", 131), ("reinmav", 64)])
 def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n):
     """RMAV_POLICY_BF16_MFMA: the same two nets on the matrix cores (bf16 operands, fp32 accumulate).  Means and
