@@ -118,8 +118,11 @@ enum rmav_integrator { RMAV_INT_EULER = 0, RMAV_INT_RK4 = 1 };
 enum rmav_policy_precision {
     RMAV_POLICY_FP32 = 0,       /* fp32 FMAs on the vector ALU */
     RMAV_POLICY_BF16_MFMA = 1,  /* bf16 operands, fp32 accumulate on the matrix cores */
-    RMAV_POLICY_FP32_MFMA = 2   /* fp32 operands and accumulate on the fp32-input matrix instructions: same precision
+    RMAV_POLICY_FP32_MFMA = 2,  /* fp32 operands and accumulate on the fp32-input matrix instructions: same precision
                                    class as RMAV_POLICY_FP32 (only the summation order differs), ~2x its speed */
+    RMAV_POLICY_F16_MFMA = 3    /* f16 operands (11-bit mantissa), fp32 accumulate, tanh folded into the next layer's weights
+                                   (csrc/rmav_policy_pair.hpp): the fastest actor and ~8x closer to the fp32 policy than bf16.
+                                   Weight buffer: rmav_pack_policy_f16 */
 };
 
 /* rmav_create flags */
@@ -203,7 +206,9 @@ enum rmav_tuning_key {
     RMAV_TUNE_STEP_LAZY = 8,       /* 1: k_step loads steps_beyond_done / reset counters only in lanes whose env terminates */
     RMAV_TUNE_SLICE_ENVS = 9,      /* E >= 64: fused rollouts as two-wavefront launches over slices of at most E envs */
     RMAV_TUNE_HOST_FLAG = 10,      /* 0: host-pointer single-wavefront steps wait with hipStreamSynchronize instead of the pinned completion word */
-    RMAV_TUNE_COUNT = 11
+    RMAV_TUNE_POLICY_PAIR = 11,    /* RMAV_POLICY_BF16_MFMA: 0 = one wavefront per 64 envs (round 3's kernel) instead of the (actor, critic) pair */
+    RMAV_TUNE_PAIR_GROUP = 12,     /* (actor, critic) wavefront pairs per workgroup of the matrix-core actors, 1 .. 4 */
+    RMAV_TUNE_COUNT = 13
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);
@@ -287,6 +292,13 @@ int64_t rmav_policy_weight_count_f32_mfma(void);
  * is re-derived from the learner's parameters). */
 int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
                      const int32_t *idx_hi, int64_t n_out, float *weights_out);
+/* RMAV_POLICY_F16_MFMA: the bf16 layout above with f16 pairs in the fragment words (same idx_lo / idx_hi maps, n_out =
+ * rmav_policy_weight_count_bf16()), and the fragments of layers 2 and 3 pre-multiplied (in fp32, before the one rounding to
+ * f16) by -2 k and -2, k = 2 log2(e): the kernel hands r = 1 / (1 + e^(2z)) = (1 - tanh z) / 2 to the next layer instead of
+ * tanh z and derives the matching biases b' = b + rowsum(W) from these rounded weights when it stages them
+ * (gym_reinmav_amd.ppo.pack_policy_weights_f16 is the torch form of the same buffer). */
+int rmav_pack_policy_f16(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                         const int32_t *idx_hi, int64_t n_out, float *weights_out);
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision);

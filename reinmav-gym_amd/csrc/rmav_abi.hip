@@ -1,9 +1,5 @@
 // rmav_abi.hip - the C ABI of include/rmav.h: handle management, launches, host/device staging.
 // There is deliberately no CPU implementation in this library: without a GPU rmav_create fails.
-#include "../../include/rmav.h"
-
-#include <hip/hip_runtime.h>
-
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -14,11 +10,9 @@
 #include <new>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types only: the RCCL entry points are resolved with dlopen/dlsym on first use
 
-#include "rmav_derive.hpp"
+#include "rmav_handle.hpp"
 #include "rmav_gae.hpp"
-#include "rmav_kernels.hpp"
 
 using namespace rmav;
 
@@ -26,98 +20,15 @@ namespace {
 
 thread_local char g_err[768] = "";
 
-int fail(int code, const char *fmt, ...) {
+}  // namespace
+
+int rmav_fail(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
 }
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(RMAV_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),       \
-                        __FILE__, __LINE__);                                                       \
-    } while (0)
-
-constexpr uint32_t kMagic = 0x524d4156u;  // 'RMAV'
-constexpr int kNumKinds = 5;
-constexpr int kStateDim[kNumKinds] = {5, 9, 10, 16, 13};
-constexpr int kActionDim[kNumKinds] = {2, 2, 4, 4, 4};
-
-}  // namespace
-
-struct rmav_env_s {
-    uint32_t magic;
-    int kind;
-    int64_t n;
-    int device;
-    uint64_t seed;
-    uint64_t env_base;
-    uint32_t flags;
-    rmav_params params;
-    hipStream_t stream;
-    bool own_stream;
-    uint64_t t;  // global step counter
-    // device-resident env data
-    float *state;
-    int32_t *sbd;
-    uint32_t *reset_cnt;
-    float *ep_ret, *last_ret;
-    int32_t *ep_len, *last_len;
-    Totals *totals;
-    double *env_time;  // RMAV_REINMAV only
-    void *arena;       // ONE allocation behind all of the arrays above (see rmav_create)
-    float *pe[3];      // per-env constants (rmav_set_env_param), nullptr = shared
-    // scratch for host-pointer calls and layout conversion (grown on demand)
-    void *scratch;
-    size_t scratch_bytes;
-    // small host-pointer calls (the gym-shaped single env, batch <= a few thousand): one block of pinned,
-    // device-mapped host memory.  The kernel reads the actions from it and writes obs / reward / done into it
-    // over PCIe, so such a call is one launch + one stream synchronise - no staging copies at all.
-    void *pinned;
-    void *pinned_dev;
-    size_t pinned_bytes;
-    // completion word of single-wavefront k_step launches through the pinned block (RolloutArgs::done_flag)
-    uint32_t *done_flag, *done_flag_dev;
-    uint32_t done_seq;
-    // statistics exchange armed for the next fused rollout launch (rmav_allgather_stats_arm): where that launch's wavefronts
-    // snapshot their envs' statistics and publish their arrival; `fired` once a launch has taken it
-    struct {
-        bool armed, fired;
-        bool allow;   // the call in progress is ONE fused launch over all envs (set by rollout_impl / rmav_rollout_policy)
-        bool stale;   // another stepping launch followed the one that took the snapshot: _post must pack again
-        struct rmav_comm_s *comm;
-        int slot;
-        int64_t cmax;
-        uint32_t seq, expected;
-    } xchg;
-    // explicit per-handle overrides of the launch heuristics (rmav_set_tuning); -1 / 0 = automatic
-    int tune[RMAV_TUNE_COUNT];
-};
-
-constexpr int kExchangeDepth = 8;   // buffer pairs of the overlapped statistics exchange
-constexpr unsigned long long kArrivalWaitTicks = 200000000ull;   // 2 s of the 100 MHz wall clock: bound of k_wait_arrivals
-struct rmav_comm_s {
-    uint32_t magic;
-    int rank, world, device;
-    ncclComm_t comm;
-    // overlapped exchange: the collective runs on the communicator's own stream, double-buffered
-    hipStream_t stream;
-    hipEvent_t ready[kExchangeDepth], done[kExchangeDepth];
-    bool used[kExchangeDepth];
-    int32_t *send[kExchangeDepth], *recv[kExchangeDepth];
-    int depth;         // buffer pairs in use (RMAV_EXCHANGE_DEPTH, 2 .. kExchangeDepth)
-    uint32_t *arrive;  // arrival words of armed launches, one per wavefront: ceil(cmax / 32) of them
-    uint32_t *flag;    // signal word (hipMallocSignalMemory): the compute stream publishes post numbers, the comm stream waits
-    int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
-    int posts;         // number of posts so far (buffer pair of post i is i % depth)
-    struct rmav_env_s *armed_by;   // the handle whose armed exchange points at this communicator (cleared by _post)
-    uint32_t *timeout_flag;        // pinned host word (device-mapped): k_wait_arrivals sets it when it gives up
-    uint32_t *timeout_flag_dev;
-};
 
 namespace {
 
@@ -137,27 +48,21 @@ struct DeviceGuard {
 };
 
 #define CHECK_HANDLE(h)                                                                            \
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");                           \
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");                           \
     DeviceGuard guard_(h->device);                                                                 \
-    if (!guard_.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", h->device)
+    if (!guard_.ok) return rmav_fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", h->device)
 
 int check_params(const rmav_params &q) {
     if (q.integrator != RMAV_INT_EULER && q.integrator != RMAV_INT_RK4)
-        return fail(RMAV_ERR_INVALID, "rmav_params.integrator must be RMAV_INT_EULER or RMAV_INT_RK4");
+        return rmav_fail(RMAV_ERR_INVALID, "rmav_params.integrator must be RMAV_INT_EULER or RMAV_INT_RK4");
     if (!(q.mass > 0) || !(q.dt > 0) || !(q.tau != 0) || !(q.mass + q.load_mass > 0))
-        return fail(RMAV_ERR_INVALID, "rmav_params: mass, dt must be > 0 and tau != 0");
+        return rmav_fail(RMAV_ERR_INVALID, "rmav_params: mass, dt must be > 0 and tau != 0");
     return RMAV_OK;
 }
 
 // slots of the per-wavefront episode totals: one per 32 envs (the fp32-MFMA policy mode runs 32 envs per wavefront)
 inline size_t n_total_slots(int64_t n) { return (size_t)((n + 31) / 32); }
 
-// Workgroup size of the one-wavefront-per-64-envs kernels: 256, or rmav_set_tuning(RMAV_TUNE_BLOCK, 64 | 128 | 256).
-inline int block_size(rmav_handle h) {
-    const int v = h->tune[RMAV_TUNE_BLOCK];
-    return (v == 64 || v == 128 || v == 256) ? v : 256;
-}
-inline dim3 grid_for(rmav_handle h) { return dim3((unsigned)((h->n + block_size(h) - 1) / block_size(h))); }
 
 int ensure_scratch(rmav_handle h, size_t bytes) {
     if (bytes <= h->scratch_bytes) return RMAV_OK;
@@ -170,7 +75,7 @@ int ensure_scratch(rmav_handle h, size_t bytes) {
     size_t want = bytes + (bytes >> 2);
     if (hipMalloc(&h->scratch, want) != hipSuccess) {
         (void)hipGetLastError();
-        return fail(RMAV_ERR_ALLOC, "hipMalloc(%zu) for scratch failed", want);
+        return rmav_fail(RMAV_ERR_ALLOC, "hipMalloc(%zu) for scratch failed", want);
     }
     h->scratch_bytes = want;
     return RMAV_OK;
@@ -192,13 +97,13 @@ int ensure_pinned(rmav_handle h, size_t bytes) {
     if (hipHostMalloc(&h->pinned, want, hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
         h->pinned = nullptr;
-        return fail(RMAV_ERR_ALLOC, "hipHostMalloc(%zu) for the pinned staging block failed", want);
+        return rmav_fail(RMAV_ERR_ALLOC, "hipHostMalloc(%zu) for the pinned staging block failed", want);
     }
     if (hipHostGetDevicePointer(&h->pinned_dev, h->pinned, 0) != hipSuccess) {
         (void)hipGetLastError();
         (void)hipHostFree(h->pinned);
         h->pinned = nullptr;
-        return fail(RMAV_ERR_HIP, "hipHostGetDevicePointer failed");
+        return rmav_fail(RMAV_ERR_HIP, "hipHostGetDevicePointer failed");
     }
     h->pinned_bytes = want;
     return RMAV_OK;
@@ -257,27 +162,11 @@ constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches bey
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     RolloutArgs a = a_in;
-    // An armed statistics exchange rides on the first call after rmav_allgather_stats_arm that is ONE fused launch over all
-    // envs (xchg.allow: rollout_impl with fused != 0 / rmav_rollout_policy; not the fused = 0 loop of single-step launches,
-    // whose first launch would snapshot the statistics T - 1 steps early, and not a sliced launch).  Any later stepping
-    // launch makes that snapshot stale, and _post then packs afresh.
-    if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;
-    if (h->xchg.armed && !h->xchg.fired && h->xchg.allow && a.slice_count == 0 && (a.flags & F_TRACK)) {
-        rmav_comm_s *c = h->xchg.comm;
-        a.xsend = c->send[h->xchg.slot];
-        a.xcmax = h->xchg.cmax;
-        a.xarrive = c->arrive;
-        a.xseq = h->xchg.seq;
-        h->xchg.expected = (uint32_t)(MODE == ACT_POLICY_F32M ? (h->n + 31) / 32 : (h->n + 63) / 64);
-        h->xchg.fired = true;
-    }
+    take_armed_exchange(h, a, 64);
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    const size_t lds = (MODE == ACT_POLICY)        ? sizeof(float) * PolicyLayout<Dims<K>::NS>::TOTAL
-                       : (MODE == ACT_POLICY_BF16) ? sizeof(float) * MfmaLayout::TOTAL
-                       : (MODE == ACT_POLICY_F32M) ? sizeof(float) * Mfma32Layout::TOTAL
-                       : (ST == ST_AOS_LDS)        ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size(h) / 64)
-                                                   : 0;
+    static_assert(!is_policy(MODE), "the policy-in-kernel rollouts are launched from rmav_policy_abi.hip");
+    const size_t lds = (ST == ST_AOS_LDS) ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size(h) / 64) : 0;
     if constexpr (is_split(MODE)) {
         // (integrator, memory wavefront) pairs: as many per workgroup as make ONE workgroup per CU (256 workgroups),
         // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_TUNE_SPLIT_GROUP = 1..8 overrides.
@@ -303,10 +192,6 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
             a.flags |= F_LEAN;
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
                            lds_per_pair * g, h->stream, a, p, pc);
-    } else if constexpr (MODE == ACT_POLICY_F32M) {   // 32 envs per wavefront (both half-waves work on the same 32 envs)
-        const int64_t per_wg = block_size(h) / 2;
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds,
-                           h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h), dim3(block_size(h)), lds, h->stream, a, p, pc);
     }
@@ -348,10 +233,7 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, boo
 
 template <int K, int MODE>
 int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
-    // the policy modes are compute-bound: one instantiation is enough there
-    if constexpr (is_policy(MODE)) {
-        return launch_rollout_kms<K, MODE, ST_DEFAULT>(h, a);
-    } else {
+    {
         if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER || MODE == ACT_BUFFER) && K != REINMAV) {
             constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : (MODE == ACT_BUFFER) ? ACT_BUFFER_SPLIT : ACT_CONTROLLER_SPLIT;
             int slices = 1;
@@ -390,12 +272,9 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     case RMAV_ACT_BUFFER: return launch_rollout_km<K, ACT_BUFFER>(h, a);
     case RMAV_ACT_RANDOM: return launch_rollout_km<K, ACT_RANDOM>(h, a);
     case RMAV_ACT_CONTROLLER: return launch_rollout_km<K, ACT_CONTROLLER>(h, a);
-    case RMAV_ACT_POLICY: return launch_rollout_km<K, ACT_POLICY>(h, a);
-    case RMAV_ACT_POLICY_BF16: return launch_rollout_km<K, ACT_POLICY_BF16>(h, a);
     case ACT_BUFFER_CTRL: return launch_rollout_kms<K, ACT_BUFFER_CTRL, ST_DEFAULT>(h, a);   // internal (rmav_step_control)
-    case ACT_POLICY_F32M: return launch_rollout_km<K, ACT_POLICY_F32M>(h, a);
     }
-    return fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
+    return rmav_fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
 
 // n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_TUNE_STEP_KERNEL = 0 falls back to k_rollout)
@@ -428,7 +307,7 @@ int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
     case RMAV_QUAD3D_SL: return launch_rollout_k<QUAD3D_SL>(h, mode, a);
     case RMAV_REINMAV: return launch_rollout_k<REINMAV>(h, mode, a);
     }
-    return fail(RMAV_ERR_INVALID, "bad kind");
+    return rmav_fail(RMAV_ERR_INVALID, "bad kind");
 }
 
 RolloutArgs base_args(rmav_handle h) {
@@ -494,14 +373,14 @@ int launch_control(rmav_handle h, float *act_dev, int layout) {
 }
 
 int check_mem_layout(int mem, int layout) {
-    if (mem != RMAV_HOST && mem != RMAV_DEVICE) return fail(RMAV_ERR_INVALID, "mem must be RMAV_HOST or RMAV_DEVICE");
-    if (layout != RMAV_SOA && layout != RMAV_AOS) return fail(RMAV_ERR_INVALID, "layout must be RMAV_SOA or RMAV_AOS");
+    if (mem != RMAV_HOST && mem != RMAV_DEVICE) return rmav_fail(RMAV_ERR_INVALID, "mem must be RMAV_HOST or RMAV_DEVICE");
+    if (layout != RMAV_SOA && layout != RMAV_AOS) return rmav_fail(RMAV_ERR_INVALID, "layout must be RMAV_SOA or RMAV_AOS");
     return RMAV_OK;
 }
 
 // Generic "copy a per-env array out of / into the handle".
 template <typename T> int copy_out(rmav_handle h, const T *dev, T *out, size_t count, int mem) {
-    if (!out) return fail(RMAV_ERR_INVALID, "output pointer is NULL");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "output pointer is NULL");
     if (mem == RMAV_DEVICE) {
         HIP_TRY(hipMemcpyAsync(out, dev, count * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     } else if (count * sizeof(T) <= kPinnedMax && ensure_pinned(h, count * sizeof(T)) == RMAV_OK) {
@@ -516,7 +395,7 @@ template <typename T> int copy_out(rmav_handle h, const T *dev, T *out, size_t c
     return RMAV_OK;
 }
 template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t count, int mem) {
-    if (!in) return fail(RMAV_ERR_INVALID, "input pointer is NULL");
+    if (!in) return rmav_fail(RMAV_ERR_INVALID, "input pointer is NULL");
     if (mem == RMAV_DEVICE) {
         HIP_TRY(hipMemcpyAsync(dev, in, count * sizeof(T), hipMemcpyDeviceToDevice, h->stream));
     } else {
@@ -565,10 +444,10 @@ int rmav_algorithmic_bytes(int kind) {
 }
 
 int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
-    if (kind < 0 || kind >= kNumKinds) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
-    if (!p) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (kind < 0 || kind >= kNumKinds) return rmav_fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (!p) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     if (reading_2d != 0 && reading_2d != 'A' && reading_2d != 'B')
-        return fail(RMAV_ERR_INVALID, "reading_2d must be 0, 'A' or 'B'");
+        return rmav_fail(RMAV_ERR_INVALID, "reading_2d must be 0, 'A' or 'B'");
     memset(p, 0, sizeof(*p));
     p->mass = 1.0;
     p->load_mass = 0.1;
@@ -622,26 +501,26 @@ int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
 
 int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t seed,
                 uint64_t env_id_base, uint32_t flags, const rmav_params *params, void *hip_stream) {
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (kind < 0 || kind >= kNumKinds) return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    if (kind < 0 || kind >= kNumKinds) return rmav_fail(RMAV_ERR_INVALID, "bad kind %d", kind);
     if (n_envs <= 0 || n_envs > ((int64_t)1 << 25))  // 32-bit buffer offsets, see rmav_kernels.hpp
-        return fail(RMAV_ERR_INVALID, "n_envs out of range: %lld", (long long)n_envs);
+        return rmav_fail(RMAV_ERR_INVALID, "n_envs out of range: %lld", (long long)n_envs);
     if (flags & ~(RMAV_F_AUTO_RESET | RMAV_F_TRACK_EPISODES))
-        return fail(RMAV_ERR_INVALID, "unknown flag bits 0x%x", flags);
+        return rmav_fail(RMAV_ERR_INVALID, "unknown flag bits 0x%x", flags);
     const int ndev = rmav_device_count();
-    if (ndev <= 0) return fail(RMAV_ERR_NO_DEVICE, "no HIP device visible; librmav has no CPU path");
-    if (device < 0 || device >= ndev) return fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    if (ndev <= 0) return rmav_fail(RMAV_ERR_NO_DEVICE, "no HIP device visible; librmav has no CPU path");
+    if (device < 0 || device >= ndev) return rmav_fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
     rmav_params pr;
     if (params) pr = *params;
     else rmav_default_params(kind, 0, &pr);
     if (int rc = check_params(pr)) return rc;
 
     DeviceGuard guard(device);
-    if (!guard.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    if (!guard.ok) return rmav_fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
 
     rmav_handle h = new (std::nothrow) rmav_env_s();
-    if (!h) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    if (!h) return rmav_fail(RMAV_ERR_ALLOC, "host allocation failed");
     memset(h, 0, sizeof(*h));
     h->magic = kMagic;
     h->kind = kind;
@@ -661,7 +540,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
             (void)hipGetLastError();
             free_all(h);
-            return fail(RMAV_ERR_HIP, "hipStreamCreate failed");
+            return rmav_fail(RMAV_ERR_HIP, "hipStreamCreate failed");
         }
         h->own_stream = true;
     }
@@ -688,7 +567,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
             (void)hipGetLastError();
             h->arena = nullptr;
             free_all(h);
-            return fail(RMAV_ERR_ALLOC, "device allocation of %zu bytes failed for %lld envs", off, (long long)n_envs);
+            return rmav_fail(RMAV_ERR_ALLOC, "device allocation of %zu bytes failed for %lld envs", off, (long long)n_envs);
         }
         char *b = (char *)h->arena;
         h->state = (float *)(b + o_state);
@@ -714,7 +593,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     }
     if (e != hipSuccess) {
         free_all(h);
-        return fail(RMAV_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+        return rmav_fail(RMAV_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
     if (kind == RMAV_REINMAV) {
         // ReinmavEnv.__init__ (reinmav_env.py:79-81): state = (0,0,0, 0,0,0, 1,0,0,0, 0,0,0), t = 0; no RNG
@@ -726,7 +605,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         if (e == hipSuccess) e = hipMemsetAsync(h->env_time, 0, n * sizeof(double), h->stream);
         if (e != hipSuccess) {
             free_all(h);
-            return fail(RMAV_ERR_HIP, "initial state failed: %s", hipGetErrorString(e));
+            return rmav_fail(RMAV_ERR_HIP, "initial state failed: %s", hipGetErrorString(e));
         }
     } else if (int rc = launch_reset(h, nullptr, RMAV_SOA)) {
         // the reference constructors call seed() then reset()  (quadrotor3d.py:73-74)
@@ -736,14 +615,14 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         free_all(h);
-        return fail(RMAV_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e));
+        return rmav_fail(RMAV_ERR_HIP, "initial reset failed: %s", hipGetErrorString(e));
     }
     *out = h;
     return RMAV_OK;
 }
 
 int rmav_destroy(rmav_handle h) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
     if (h->xchg.comm && h->xchg.comm->armed_by == h) h->xchg.comm->armed_by = nullptr;
     DeviceGuard guard(h->device);
     (void)hipStreamSynchronize(h->stream);
@@ -760,15 +639,15 @@ int rmav_seed(rmav_handle h, uint64_t seed) {
 }
 
 int rmav_get_params(rmav_handle h, rmav_params *out) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     *out = h->params;
     return RMAV_OK;
 }
 
 int rmav_set_params(rmav_handle h, const rmav_params *in) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    if (!in) return fail(RMAV_ERR_INVALID, "in is NULL");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!in) return rmav_fail(RMAV_ERR_INVALID, "in is NULL");
     if (int rc = check_params(*in)) return rc;
     h->params = *in;
     return RMAV_OK;
@@ -795,8 +674,8 @@ int rmav_set_stream(rmav_handle h, void *hip_stream) {
 int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    if (which < 0 || which > 2) return fail(RMAV_ERR_INVALID, "unknown env param %d", which);
-    if (h->kind == RMAV_REINMAV) return fail(RMAV_ERR_INVALID, "per-env constants are for the quadrotor kinds");
+    if (which < 0 || which > 2) return rmav_fail(RMAV_ERR_INVALID, "unknown env param %d", which);
+    if (h->kind == RMAV_REINMAV) return rmav_fail(RMAV_ERR_INVALID, "per-env constants are for the quadrotor kinds");
     if (!values) {  // back to the shared value
         if (h->pe[which]) {
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -808,26 +687,26 @@ int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem) {
     if (!h->pe[which] && hipMalloc((void **)&h->pe[which], (size_t)h->n * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         h->pe[which] = nullptr;
-        return fail(RMAV_ERR_ALLOC, "device allocation failed");
+        return rmav_fail(RMAV_ERR_ALLOC, "device allocation failed");
     }
     return copy_in(h, h->pe[which], values, (size_t)h->n, mem);
 }
 
 int rmav_set_tuning(rmav_handle h, int key, int value) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    if (key < 0 || key >= RMAV_TUNE_COUNT) return fail(RMAV_ERR_INVALID, "unknown tuning key %d", key);
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (key < 0 || key >= RMAV_TUNE_COUNT) return rmav_fail(RMAV_ERR_INVALID, "unknown tuning key %d", key);
     h->tune[key] = value;
     return RMAV_OK;
 }
 int rmav_get_tuning(rmav_handle h, int key, int *value_out) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    if (key < 0 || key >= RMAV_TUNE_COUNT || !value_out) return fail(RMAV_ERR_INVALID, "unknown tuning key %d or NULL out", key);
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (key < 0 || key >= RMAV_TUNE_COUNT || !value_out) return rmav_fail(RMAV_ERR_INVALID, "unknown tuning key %d or NULL out", key);
     *value_out = h->tune[key];
     return RMAV_OK;
 }
 
 int64_t rmav_num_envs(rmav_handle h) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
     return h->n;
 }
 
@@ -860,13 +739,13 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
                         int fused) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
-    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (n_steps <= 0) return rmav_fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (action_mode < RMAV_ACT_BUFFER || action_mode > RMAV_ACT_CONTROLLER)
-        return fail(RMAV_ERR_INVALID, "unknown action_mode %d", action_mode);
+        return rmav_fail(RMAV_ERR_INVALID, "unknown action_mode %d", action_mode);
     if (action_mode == RMAV_ACT_BUFFER && !actions_in)
-        return fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
+        return rmav_fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
     if (ctrl_out && h->kind == RMAV_REINMAV)
-        return fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (the controller action mode); there is no separate control()");
+        return rmav_fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (the controller action mode); there is no separate control()");
     const size_t n = (size_t)h->n, T = (size_t)n_steps;
     const size_t nS = kStateDim[h->kind], nA = kActionDim[h->kind];
     const size_t b_act = T * nA * n * sizeof(float), b_obs = T * nS * n * sizeof(float);
@@ -1003,8 +882,8 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
 
 int rmav_step_control(rmav_handle h, const float *actions, float *obs_out, float *rew_out, uint8_t *done_out,
                       float *next_actions_out, int mem, int layout) {
-    if (!actions) return fail(RMAV_ERR_INVALID, "actions is NULL");
-    if (!next_actions_out) return fail(RMAV_ERR_INVALID, "next_actions_out is NULL");
+    if (!actions) return rmav_fail(RMAV_ERR_INVALID, "actions is NULL");
+    if (!next_actions_out) return rmav_fail(RMAV_ERR_INVALID, "next_actions_out is NULL");
     return rollout_impl(h, 1, RMAV_ACT_BUFFER, actions, nullptr, obs_out, rew_out, done_out, next_actions_out, mem,
                         layout, 1);
 }
@@ -1023,45 +902,62 @@ int64_t rmav_policy_weight_count(int kind) {
     case RMAV_QUAD3D_SL: return PolicyLayout<16>::TOTAL;
     case RMAV_REINMAV: return PolicyLayout<13>::TOTAL;
     }
-    return fail(RMAV_ERR_INVALID, "bad kind %d", kind);
+    return rmav_fail(RMAV_ERR_INVALID, "bad kind %d", kind);
 }
 
 int64_t rmav_policy_weight_count_bf16(void) { return MfmaLayout::TOTAL; }
 int64_t rmav_policy_weight_count_f32_mfma(void) { return Mfma32Layout::TOTAL; }
 
-int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
-                     const int32_t *idx_hi, int64_t n_out, float *weights_out) {
+static int pack_policy_impl(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                            const int32_t *idx_hi, int64_t n_out, float *weights_out, bool f16) {
     CHECK_HANDLE(h);
-    if (n_params <= 0 || n_params > kPackMaxParams) return fail(RMAV_ERR_INVALID, "n_params must be in [1, %d]", kPackMaxParams);
+    if (n_params <= 0 || n_params > kPackMaxParams) return rmav_fail(RMAV_ERR_INVALID, "n_params must be in [1, %d]", kPackMaxParams);
     if (!params || !sizes || !idx_lo || !idx_hi || !weights_out || n_out <= 0)
-        return fail(RMAV_ERR_INVALID, "params, sizes, idx_lo, idx_hi, weights_out are required and n_out > 0");
+        return rmav_fail(RMAV_ERR_INVALID, "params, sizes, idx_lo, idx_hi, weights_out are required and n_out > 0");
     PackSrc src;
     memset(&src, 0, sizeof(src));
     int64_t end = 0;
     for (int k = 0; k < n_params; ++k) {
-        if (!params[k] || sizes[k] < 0) return fail(RMAV_ERR_INVALID, "parameter %d is NULL or has a negative size", k);
+        if (!params[k] || sizes[k] < 0) return rmav_fail(RMAV_ERR_INVALID, "parameter %d is NULL or has a negative size", k);
         end += sizes[k];
-        if (end > 0x7fffffff) return fail(RMAV_ERR_INVALID, "too many parameter elements");
+        if (end > 0x7fffffff) return rmav_fail(RMAV_ERR_INVALID, "too many parameter elements");
         src.p[k] = params[k];
         src.end[k] = (int32_t)end;
     }
     src.n = n_params;
-    hipLaunchKernelGGL(k_pack_policy, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, h->stream, src, idx_lo, idx_hi, n_out, weights_out);
+    const dim3 grid((unsigned)((n_out + 255) / 256));
+    if (f16) {
+        if (n_out != MfmaLayout::TOTAL) return rmav_fail(RMAV_ERR_INVALID, "n_out must be rmav_policy_weight_count_bf16() = %d", (int)MfmaLayout::TOTAL);
+        hipLaunchKernelGGL(k_pack_policy<true>, grid, dim3(256), 0, h->stream, src, idx_lo, idx_hi, n_out, weights_out, (int32_t)MfmaLayout::NET,
+                           (int32_t)MfmaLayout::A2, (int32_t)MfmaLayout::A3, (int32_t)MfmaLayout::B1, -2.0f * kTanhScale, -2.0f);
+    } else {
+        hipLaunchKernelGGL(k_pack_policy<false>, grid, dim3(256), 0, h->stream, src, idx_lo, idx_hi, n_out, weights_out, 1, 0, 0, 0, 1.0f, 1.0f);
+    }
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
+}
+
+int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                     const int32_t *idx_hi, int64_t n_out, float *weights_out) {
+    return pack_policy_impl(h, n_params, params, sizes, idx_lo, idx_hi, n_out, weights_out, false);
+}
+int rmav_pack_policy_f16(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
+                         const int32_t *idx_hi, int64_t n_out, float *weights_out) {
+    return pack_policy_impl(h, n_params, params, sizes, idx_lo, idx_hi, n_out, weights_out, true);
 }
 
 int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision) {
     CHECK_HANDLE(h);
-    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA && precision != RMAV_POLICY_FP32_MFMA)
-        return fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32, RMAV_POLICY_BF16_MFMA or RMAV_POLICY_FP32_MFMA");
-    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA && precision != RMAV_POLICY_FP32_MFMA &&
+        precision != RMAV_POLICY_F16_MFMA)
+        return rmav_fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32, RMAV_POLICY_BF16_MFMA, RMAV_POLICY_FP32_MFMA or RMAV_POLICY_F16_MFMA");
+    if (n_steps <= 0) return rmav_fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (!weights || !logp_out || !value_out)
-        return fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
+        return rmav_fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
     if ((reinterpret_cast<uintptr_t>(weights) & 15u) != 0)
-        return fail(RMAV_ERR_INVALID, "weights must be 16-byte aligned");
+        return rmav_fail(RMAV_ERR_INVALID, "weights must be 16-byte aligned");
     RolloutArgs a = base_args(h);
     a.n_steps = n_steps;
     a.act_out = actions_out;
@@ -1071,16 +967,19 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
     a.policy_w = weights;
     a.logp_out = logp_out;
     a.val_out = value_out;
-    const int kmode = precision == RMAV_POLICY_FP32 ? (int)RMAV_ACT_POLICY : precision == RMAV_POLICY_BF16_MFMA ? (int)RMAV_ACT_POLICY_BF16 : (int)ACT_POLICY_F32M;
+    const int kmode = precision == RMAV_POLICY_FP32        ? (int)RMAV_ACT_POLICY
+                      : precision == RMAV_POLICY_BF16_MFMA ? (int)RMAV_ACT_POLICY_BF16
+                      : precision == RMAV_POLICY_F16_MFMA  ? (int)ACT_POLICY_F16
+                                                           : (int)ACT_POLICY_F32M;
     h->xchg.allow = true;
-    if (int rc = launch_rollout(h, kmode, a)) return rc;
+    if (int rc = rmav_launch_policy_rollout(h, kmode, a)) return rc;
     h->t += (uint64_t)n_steps;
     return RMAV_OK;
 }
 
 int rmav_step(rmav_handle h, const float *actions, float *obs_out, float *rew_out,
               uint8_t *done_out, int mem, int layout) {
-    if (!actions) return fail(RMAV_ERR_INVALID, "actions is NULL");
+    if (!actions) return rmav_fail(RMAV_ERR_INVALID, "actions is NULL");
     return rmav_rollout(h, 1, RMAV_ACT_BUFFER, actions, nullptr, obs_out, rew_out, done_out, mem,
                         layout, 1);
 }
@@ -1088,7 +987,7 @@ int rmav_step(rmav_handle h, const float *actions, float *obs_out, float *rew_ou
 int rmav_control(rmav_handle h, float *actions_out, int mem, int layout) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
-    if (!actions_out) return fail(RMAV_ERR_INVALID, "actions_out is NULL");
+    if (!actions_out) return rmav_fail(RMAV_ERR_INVALID, "actions_out is NULL");
     const size_t nact = (size_t)h->n * kActionDim[h->kind];
     if (mem == RMAV_DEVICE) return launch_control(h, actions_out, layout);
     if (nact * sizeof(float) <= kPinnedMax && ensure_pinned(h, nact * sizeof(float)) == RMAV_OK) {   // zero-copy
@@ -1105,7 +1004,7 @@ int rmav_control(rmav_handle h, float *actions_out, int mem, int layout) {
 int rmav_get_state(rmav_handle h, float *out, int mem, int layout) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     const int nS = kStateDim[h->kind];
     const size_t cnt = (size_t)h->n * nS;
     if (layout == RMAV_SOA) return copy_out(h, (const float *)h->state, out, cnt, mem);
@@ -1124,7 +1023,7 @@ int rmav_get_state(rmav_handle h, float *out, int mem, int layout) {
 int rmav_set_state(rmav_handle h, const float *in, int mem, int layout) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
-    if (!in) return fail(RMAV_ERR_INVALID, "in is NULL");
+    if (!in) return rmav_fail(RMAV_ERR_INVALID, "in is NULL");
     const int nS = kStateDim[h->kind];
     const size_t cnt = (size_t)h->n * nS;
     if (layout == RMAV_SOA) return copy_in(h, h->state, in, cnt, mem);
@@ -1164,41 +1063,41 @@ int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem) {
 int rmav_get_time(rmav_handle h, double *out, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
+    if (!h->env_time) return rmav_fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
     return copy_out(h, (const double *)h->env_time, out, (size_t)h->n, mem);
 }
 int rmav_set_time(rmav_handle h, const double *in, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    if (!h->env_time) return fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
+    if (!h->env_time) return rmav_fail(RMAV_ERR_INVALID, "only reinmav envs carry their own clock");
     return copy_in(h, h->env_time, in, (size_t)h->n, mem);
 }
 
 int rmav_get_step_count(rmav_handle h, uint64_t *out) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     *out = h->t;
     return RMAV_OK;
 }
 int rmav_set_step_count(rmav_handle h, uint64_t t) {
-    if (!valid(h)) return fail(RMAV_ERR_INVALID, "invalid rmav_handle");
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
     h->t = t;
     return RMAV_OK;
 }
 
 int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear) {
     CHECK_HANDLE(h);
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
-        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+        return rmav_fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
     const size_t nw = n_total_slots(h->n);
     Totals *host = new (std::nothrow) Totals[nw];
-    if (!host) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    if (!host) return rmav_fail(RMAV_ERR_ALLOC, "host allocation failed");
     hipError_t e = hipMemcpyAsync(host, h->totals, nw * sizeof(Totals), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) {
         delete[] host;
-        return fail(RMAV_ERR_HIP, "reading episode totals failed: %s", hipGetErrorString(e));
+        return rmav_fail(RMAV_ERR_HIP, "reading episode totals failed: %s", hipGetErrorString(e));
     }
     out->episodes = 0;
     out->return_sum = 0.0;
@@ -1218,7 +1117,7 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
-        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+        return rmav_fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
     const size_t n = (size_t)h->n;
     const hipMemcpyKind kind = (mem == RMAV_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (last_return) HIP_TRY(hipMemcpyAsync(last_return, h->last_ret, n * sizeof(float), kind, h->stream));
@@ -1233,9 +1132,9 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
 int rmav_gae(rmav_handle h, int32_t n_steps, const float *rew, const uint8_t *done, const float *values,
              float gamma, float lam, float reward_scale, float *adv_out, float *ret_out, double *sums_out) {
     CHECK_HANDLE(h);
-    if (n_steps <= 0) return fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (n_steps <= 0) return rmav_fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (!rew || !done || !values || !adv_out || !ret_out)
-        return fail(RMAV_ERR_INVALID, "rew, done, values, adv_out and ret_out are required (device pointers)");
+        return rmav_fail(RMAV_ERR_INVALID, "rew, done, values, adv_out and ret_out are required (device pointers)");
     const unsigned nblk = (unsigned)((h->n + 255) / 256);
     double *partial = nullptr;
     if (sums_out) {
@@ -1254,8 +1153,8 @@ int rmav_gae(rmav_handle h, int32_t n_steps, const float *rew, const uint8_t *do
 
 int rmav_normalize(rmav_handle h, float *x, int64_t count, float mean, float rstd) {
     CHECK_HANDLE(h);
-    if (!x || count < 0) return fail(RMAV_ERR_INVALID, "x is NULL or count < 0");
-    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return fail(RMAV_ERR_INVALID, "x must be 16-byte aligned");
+    if (!x || count < 0) return rmav_fail(RMAV_ERR_INVALID, "x is NULL or count < 0");
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return rmav_fail(RMAV_ERR_INVALID, "x must be 16-byte aligned");
     if (count == 0) return RMAV_OK;
     int64_t blocks = (count / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -1302,14 +1201,14 @@ constexpr uint32_t kCommMagic = 0x524d4143u;  // 'RMAC'
     do {                                                                                           \
         ncclResult_t r_ = (expr);                                                                  \
         if (r_ != ncclSuccess)                                                                     \
-            return fail(RMAV_ERR_HIP, "%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(r_) : "RCCL error"); \
+            return rmav_fail(RMAV_ERR_HIP, "%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(r_) : "RCCL error"); \
     } while (0)
 }  // namespace
 
 int rmav_comm_unique_id(void *id_out) {
-    if (!id_out) return fail(RMAV_ERR_INVALID, "id_out is NULL");
+    if (!id_out) return rmav_fail(RMAV_ERR_INVALID, "id_out is NULL");
     RcclApi *R = rccl();
-    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    if (!R) return rmav_fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
     ncclUniqueId id;
     RCCL_TRY(R->GetUniqueId(&id));
     static_assert(sizeof(id) == RMAV_COMM_ID_BYTES, "RCCL unique id size");
@@ -1318,20 +1217,20 @@ int rmav_comm_unique_id(void *id_out) {
 }
 
 int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device) {
-    if (!out) return fail(RMAV_ERR_INVALID, "out is NULL");
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "out is NULL");
     *out = nullptr;
-    if (!id || world <= 0 || rank < 0 || rank >= world) return fail(RMAV_ERR_INVALID, "need id and 0 <= rank < world");
+    if (!id || world <= 0 || rank < 0 || rank >= world) return rmav_fail(RMAV_ERR_INVALID, "need id and 0 <= rank < world");
     const int ndev = rmav_device_count();
-    if (ndev <= 0) return fail(RMAV_ERR_NO_DEVICE, "no HIP device visible");
-    if (device < 0 || device >= ndev) return fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    if (ndev <= 0) return rmav_fail(RMAV_ERR_NO_DEVICE, "no HIP device visible");
+    if (device < 0 || device >= ndev) return rmav_fail(RMAV_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
     RcclApi *R = rccl();
-    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    if (!R) return rmav_fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
     DeviceGuard guard(device);
-    if (!guard.ok) return fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
+    if (!guard.ok) return rmav_fail(RMAV_ERR_HIP, "hipSetDevice(%d) failed", device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     rmav_comm c = new (std::nothrow) rmav_comm_s();
-    if (!c) return fail(RMAV_ERR_ALLOC, "host allocation failed");
+    if (!c) return rmav_fail(RMAV_ERR_ALLOC, "host allocation failed");
     memset(c, 0, sizeof(*c));
     c->magic = kCommMagic;
     c->rank = rank;
@@ -1340,7 +1239,7 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     ncclResult_t r = R->CommInitRank(&c->comm, world, uid, rank);
     if (r != ncclSuccess) {
         delete c;
-        return fail(RMAV_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+        return rmav_fail(RMAV_ERR_HIP, "ncclCommInitRank failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
     }
     // A high-priority stream: HIP multiplexes all streams of one priority onto a few hardware queues (GPU_MAX_HW_QUEUES,
     // 4 by default) round-robin, and a process that also runs torch has dozens - when the communicator's stream lands on
@@ -1365,7 +1264,7 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)rmav_comm_destroy(c);
-        return fail(RMAV_ERR_HIP, "stream / event creation for the communicator failed: %s", hipGetErrorString(e));
+        return rmav_fail(RMAV_ERR_HIP, "stream / event creation for the communicator failed: %s", hipGetErrorString(e));
     }
     // Hand-over from the compute stream to the communicator's stream without an event: hipEventRecord puts a barrier
     // packet into the COMPUTE stream (~8 us in front of the next rollout launch, measured); a one-thread kernel that
@@ -1386,7 +1285,7 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
 }
 
 int rmav_comm_destroy(rmav_comm c) {
-    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (!c || c->magic != kCommMagic) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_comm");
     DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     RcclApi *R = rccl();
@@ -1414,8 +1313,8 @@ int rmav_comm_destroy(rmav_comm c) {
 int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
     CHECK_HANDLE(h);
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
-        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
-    if (!send_out || cmax < h->n) return fail(RMAV_ERR_INVALID, "send_out is NULL or cmax < num_envs");
+        return rmav_fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    if (!send_out || cmax < h->n) return rmav_fail(RMAV_ERR_INVALID, "send_out is NULL or cmax < num_envs");
     hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
                        (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, send_out);
     HIP_TRY(hipGetLastError());
@@ -1425,15 +1324,15 @@ int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
 namespace {
 // shard of rank c->rank out of n_total, checked against the handle
 int check_shard(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out) {
-    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (!c || c->magic != kCommMagic) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_comm");
     if (!(h->flags & RMAV_F_TRACK_EPISODES))
-        return fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
-    if (c->device != h->device) return fail(RMAV_ERR_INVALID, "communicator and handle live on different devices");
+        return rmav_fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
+    if (c->device != h->device) return rmav_fail(RMAV_ERR_INVALID, "communicator and handle live on different devices");
     const int64_t W = c->world, base = n_total / W, rem = n_total % W;
-    if (n_total <= 0 || base == 0) return fail(RMAV_ERR_INVALID, "n_total must be >= the number of ranks");
+    if (n_total <= 0 || base == 0) return rmav_fail(RMAV_ERR_INVALID, "n_total must be >= the number of ranks");
     const int64_t count = base + (c->rank < rem ? 1 : 0), start = c->rank * base + (c->rank < rem ? c->rank : rem);
     if (h->n != count || (int64_t)h->env_base != start)
-        return fail(RMAV_ERR_INVALID, "rank %d of %d must own envs [%lld, %lld) of %lld; the handle owns [%llu, %llu)", c->rank,
+        return rmav_fail(RMAV_ERR_INVALID, "rank %d of %d must own envs [%lld, %lld) of %lld; the handle owns [%llu, %llu)", c->rank,
                     c->world, (long long)start, (long long)(start + count), (long long)n_total,
                     (unsigned long long)h->env_base, (unsigned long long)(h->env_base + (uint64_t)h->n));
     *cmax_out = base + (rem ? 1 : 0);
@@ -1447,7 +1346,7 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
     int64_t cmax = 0;
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     RcclApi *R = rccl();
-    if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    if (!R) return rmav_fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
     if (cmax > c->cmax) {   // (re)allocate the buffer pairs
         HIP_TRY(hipStreamSynchronize(c->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1460,7 +1359,7 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
                 hipMalloc((void **)&c->recv[k], (size_t)(2 * cmax) * sizeof(int32_t) * (size_t)c->world) != hipSuccess) {
                 (void)hipGetLastError();
                 c->cmax = 0;
-                return fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
+                return rmav_fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
             }
             // an armed launch writes only this rank's envs: the padding up to cmax stays zero from here on
             HIP_TRY(hipMemsetAsync(c->send[k], 0, (size_t)(2 * cmax) * sizeof(int32_t), c->stream));
@@ -1471,7 +1370,7 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
         if (hipMalloc((void **)&c->arrive, words * sizeof(uint32_t)) != hipSuccess) {
             (void)hipGetLastError();
             c->cmax = 0;
-            return fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
+            return rmav_fail(RMAV_ERR_ALLOC, "device allocation for the exchange buffers failed");
         }
         HIP_TRY(hipMemsetAsync(c->arrive, 0, words * sizeof(uint32_t), c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1496,7 +1395,7 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
 
 int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total) {
     CHECK_HANDLE(h);
-    if (h->xchg.armed) return fail(RMAV_ERR_INVALID, "an exchange is already armed on this handle: post it first");
+    if (h->xchg.armed) return rmav_fail(RMAV_ERR_INVALID, "an exchange is already armed on this handle: post it first");
     int64_t cmax = 0;
     int k = 0;
     if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) return rc;
@@ -1518,11 +1417,11 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     int k = 0;
     RcclApi *R = rccl();
     const bool armed = h->xchg.armed;
-    if (armed && h->xchg.comm != c) return fail(RMAV_ERR_INVALID, "the handle's armed exchange belongs to another communicator");
+    if (armed && h->xchg.comm != c) return rmav_fail(RMAV_ERR_INVALID, "the handle's armed exchange belongs to another communicator");
     if (armed) {   // allocated and back-pressured when it was armed
-        if (!R) return fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+        if (!R) return rmav_fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
         if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
-        if (cmax != h->xchg.cmax) return fail(RMAV_ERR_INVALID, "n_total differs from the armed exchange's");
+        if (cmax != h->xchg.cmax) return rmav_fail(RMAV_ERR_INVALID, "n_total differs from the armed exchange's");
         cmax = h->xchg.cmax;
         k = h->xchg.slot;
         h->xchg.armed = false;
@@ -1531,7 +1430,7 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     } else if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) {
         return rc;
     }
-    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an earlier armed exchange never saw its rollout launch complete");
+    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an earlier armed exchange never saw its rollout launch complete");
     if (armed && h->xchg.fired && !h->xchg.stale) {
         // the rollout launch itself wrote the snapshot and its wavefronts' arrival words: nothing enters the compute stream.
         // The wait is bounded (kArrivalWaitTicks of the 100 MHz clock): if the armed launch never completes, the waiter raises
@@ -1564,9 +1463,9 @@ int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, flo
     CHECK_HANDLE(h);
     int64_t cmax = 0;
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
-    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
-    if (c->posts == 0 || cmax != c->cmax) return fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
-    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
+    if (!returns_out || !lengths_out) return rmav_fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
+    if (c->posts == 0 || cmax != c->cmax) return rmav_fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
+    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
     const int k = (c->posts - 1) % c->depth;
     HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
@@ -1576,7 +1475,7 @@ int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, flo
 }
 
 int rmav_allgather_stats_wait(rmav_comm c, double timeout_s) {
-    if (!c || c->magic != kCommMagic) return fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (!c || c->magic != kCommMagic) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_comm");
     if (c->posts == 0) return RMAV_OK;
     DeviceGuard guard(c->device);
     const int k = (c->posts - 1) % c->depth;
@@ -1585,21 +1484,21 @@ int rmav_allgather_stats_wait(rmav_comm c, double timeout_s) {
     for (;;) {
         const hipError_t e = hipEventQuery(c->done[k]);
         if (e == hipSuccess) break;
-        if (e != hipErrorNotReady) return fail(RMAV_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
+        if (e != hipErrorNotReady) return rmav_fail(RMAV_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
         (void)hipGetLastError();
         timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if (timeout_s >= 0 && (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s)
-            return fail(RMAV_ERR_TIMEOUT, "the posted exchange did not complete within %.3f s", timeout_s);
+            return rmav_fail(RMAV_ERR_TIMEOUT, "the posted exchange did not complete within %.3f s", timeout_s);
         timespec nap = {0, 50000};
         nanosleep(&nap, nullptr);
     }
-    if (*c->timeout_flag) return fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
+    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
     return RMAV_OK;
 }
 
 int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out) {
-    if (!returns_out || !lengths_out) return fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
+    if (!returns_out || !lengths_out) return rmav_fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
     if (int rc = rmav_allgather_stats_post(h, c, n_total)) return rc;
     return rmav_allgather_stats_result(h, c, n_total, returns_out, lengths_out);
 }

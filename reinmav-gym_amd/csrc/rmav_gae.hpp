@@ -150,8 +150,12 @@ __device__ __forceinline__ float pack_fetch(const PackSrc &src, int32_t j) {
     }
     return 0.0f;   // the appended zero (padding)
 }
+// F16: the pair words are f16 (round to nearest even) and word i of the MfmaLayout buffer is pre-scaled by `scale2` inside
+// the layer-2 fragments, by `scale3` inside the layer-3 fragments (rmav_pack_policy_f16: tanh folded into the next layer).
+template <bool F16>
 __global__ __launch_bounds__(256) void k_pack_policy(const PackSrc src, const int32_t *__restrict__ lo, const int32_t *__restrict__ hi,
-                                                     int64_t n_out, float *__restrict__ out) {
+                                                     int64_t n_out, float *__restrict__ out, int32_t net_words, int32_t a2_begin,
+                                                     int32_t a3_begin, int32_t a3_end, float scale2, float scale3) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     const float a = pack_fetch(src, lo[i]);
@@ -160,9 +164,17 @@ __global__ __launch_bounds__(256) void k_pack_policy(const PackSrc src, const in
         out[i] = a;
     } else {
         typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-        const f32x2_t v = {a, pack_fetch(src, h)};
-        out[i] = __builtin_bit_cast(float, __builtin_convertvector(v, bf16x2_t));   // round to nearest even, as torch's .to(bfloat16)
+        f32x2_t v = {a, pack_fetch(src, h)};
+        if constexpr (F16) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+            const int32_t o = (int32_t)(i % net_words);
+            const float sc = (i < 2 * (int64_t)net_words && o >= a2_begin && o < a3_end) ? (o < a3_begin ? scale2 : scale3) : 1.0f;
+            v = v * sc;
+            out[i] = __builtin_bit_cast(float, __builtin_convertvector(v, f16x2_t));
+        } else {
+            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+            out[i] = __builtin_bit_cast(float, __builtin_convertvector(v, bf16x2_t));   // round to nearest even, as torch's .to(bfloat16)
+        }
     }
 }
 

@@ -41,7 +41,9 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
               // the fp32 policy on the fp32-input matrix instructions (rmav_policy_mfma32.hpp)
               ACT_POLICY_F32M = 8,
               // internal: ACT_BUFFER with the memory wavefront prefetching the caller's actions into the hand-over tile
-              ACT_BUFFER_SPLIT = 9 };
+              ACT_BUFFER_SPLIT = 9,
+              // the f16 matrix-core actor (RMAV_POLICY_F16_MFMA): only as an (actor, critic) wavefront pair, rmav_policy_pair.hpp
+              ACT_POLICY_F16 = 10 };
 constexpr bool is_mfma_policy(int mode) { return mode == ACT_POLICY_BF16 || mode == ACT_POLICY_F32M; }
 constexpr bool is_policy(int mode) { return mode == ACT_POLICY || is_mfma_policy(mode); }
 constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT || mode == ACT_BUFFER_SPLIT; }
@@ -1070,9 +1072,10 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 atomicAdd(&slot->return_sum, (double)fin_ret);
             }
         } else if (__ballot(fin_n != 0) != 0) {
-            const unsigned int wn = wave_sum(fin_n);
-            const unsigned int wl = wave_sum(fin_len);
-            const float wr = wave_sum(fin_ret);
+            // (the matrix-core actors keep ds_bpermute out of their kernels: rmav_policy_mfma.hpp, xor32)
+            const unsigned int wn = is_mfma_policy(MODE) ? wave_sum_x(fin_n) : wave_sum(fin_n);
+            const unsigned int wl = is_mfma_policy(MODE) ? wave_sum_x(fin_len) : wave_sum(fin_len);
+            const float wr = is_mfma_policy(MODE) ? wave_sum_x(fin_ret) : wave_sum(fin_ret);
             if ((threadIdx.x & 63) == 0) {
                 atomicAdd(&slot->episodes, (unsigned long long)wn);
                 atomicAdd(&slot->length_sum, (unsigned long long)wl);
@@ -1387,7 +1390,7 @@ __global__ __launch_bounds__(kBlock) void k_control(const float *state, int64_t 
 }
 
 // ReinmavEnv: the built-in controller's command (F, Mx, My, Mz) at the env's current (state, t)
-__global__ __launch_bounds__(kBlock) void k_control_reinmav(const float *state, const double *env_time, int64_t n,
+[[maybe_unused]] static __global__ __launch_bounds__(kBlock) void k_control_reinmav(const float *state, const double *env_time, int64_t n,
                                                             float *act_out, uint32_t flags, const ReinmavP p) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1408,12 +1411,12 @@ __global__ __launch_bounds__(kBlock) void k_control_reinmav(const float *state, 
 }
 
 // [dim][n] <-> [n][dim]
-__global__ __launch_bounds__(kBlock) void k_soa_to_aos(const float *src, float *dst, int64_t n, int dim) {
+[[maybe_unused]] static __global__ __launch_bounds__(kBlock) void k_soa_to_aos(const float *src, float *dst, int64_t n, int dim) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int c = 0; c < dim; ++c) dst[i * dim + c] = src[(int64_t)c * n + i];
 }
-__global__ __launch_bounds__(kBlock) void k_aos_to_soa(const float *src, float *dst, int64_t n, int dim) {
+[[maybe_unused]] static __global__ __launch_bounds__(kBlock) void k_aos_to_soa(const float *src, float *dst, int64_t n, int dim) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int c = 0; c < dim; ++c) dst[(int64_t)c * n + i] = src[i * dim + c];

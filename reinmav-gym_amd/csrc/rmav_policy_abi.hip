@@ -1,0 +1,73 @@
+// rmav_policy_abi.hip - launches of the policy-in-kernel rollouts (rmav_rollout_policy); the second translation unit of librmav.so.
+//
+// Compiled with -fno-slp-vectorize.  hipcc's SLP vectoriser packs adjacent scalar fp32 operations of the dynamics into
+// v_pk_mul / v_pk_fma / v_pk_add_f32 / v_pk_mov_b32 with cross-register op_sel selects.  In kernels that also issue MFMAs, with
+// more than one such wavefront per SIMD, a read one or two instructions behind such a packed write returned the register's
+// PREVIOUS contents in lanes 48..63 (profiles/r04/packed_f32_hazard.md: x-axis thrust term of quadrotor3d's step lost,
+// 7 - 25 % of the wavefronts of an f16-actor rollout, ~1 % for bf16, ~0.1 % for round 3's one-wavefront bf16 kernel at
+// 262 144 envs; never with one wavefront per SIMD, never in the MFMA-free kernels, which tests and tools/determinism.py
+// cover at 2 - 4 wavefronts per SIMD).  Without the vectoriser: 0 differing bits in 40 rollouts of every variant, and the
+// kernels are no slower (packed fp32 beside MFMAs costs more than it saves, /opt/skills/guides/MI355X_MICROARCH.md).
+// tests/test_gpu_ppo.py::test_matrix_core_actors_are_deterministic guards it; tests/test_resource_usage.py pins that these
+// kernels contain no compiler-made packed fp32 arithmetic.
+#include "rmav_handle.hpp"
+#include "rmav_policy_pair.hpp"
+
+using namespace rmav;
+
+namespace {
+
+// one wavefront per 64 envs (32 for the fp32-MFMA actor: both half-waves work on the same 32 envs)
+template <int K, int MODE> int launch_policy_1w(rmav_handle h, const RolloutArgs &a_in) {
+    RolloutArgs a = a_in;
+    take_armed_exchange(h, a, MODE == ACT_POLICY_F32M ? 32 : 64);
+    const typename Env<K>::P p = derive_env<K>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params);
+    const size_t lds = sizeof(float) * (MODE == ACT_POLICY ? (size_t)PolicyLayout<Dims<K>::NS>::TOTAL
+                                        : MODE == ACT_POLICY_BF16 ? (size_t)MfmaLayout::TOTAL : (size_t)Mfma32Layout::TOTAL);
+    const int64_t per_wg = MODE == ACT_POLICY_F32M ? block_size(h) / 2 : block_size(h);
+    hipLaunchKernelGGL((k_rollout<K, MODE, ST_DEFAULT>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds, h->stream,
+                       a, p, pc);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+// The matrix-core actors as (actor, critic) wavefront pairs (rmav_policy_pair.hpp).  Pairs per workgroup: the pairs of a
+// workgroup share one LDS copy of the weights (30 KB) but also one s_barrier; RMAV_TUNE_PAIR_GROUP = 1 .. 4 overrides.
+template <int K, int FMT> int launch_rollout_pair(rmav_handle h, const RolloutArgs &a_in) {
+    RolloutArgs a = a_in;
+    take_armed_exchange(h, a, 64);
+    const typename Env<K>::P p = derive_env<K>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params);
+    const int forced = h->tune[RMAV_TUNE_PAIR_GROUP];
+    const int g = (forced >= 1 && forced <= kPairGroupMax) ? forced : kPairGroupDefault;
+    const int64_t per_wg = 64 * g;
+    hipLaunchKernelGGL((k_rollout_pair<K, FMT>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g), pair_lds_bytes<K>(g),
+                       h->stream, a, p, pc);
+    HIP_TRY(hipGetLastError());
+    return RMAV_OK;
+}
+
+template <int K> int launch_policy_k(rmav_handle h, int kmode, const RolloutArgs &a) {
+    switch (kmode) {
+    case RMAV_ACT_POLICY: return launch_policy_1w<K, ACT_POLICY>(h, a);
+    case RMAV_ACT_POLICY_BF16:
+        return h->tune[RMAV_TUNE_POLICY_PAIR] == 0 ? launch_policy_1w<K, ACT_POLICY_BF16>(h, a) : launch_rollout_pair<K, FMT_BF16>(h, a);
+    case ACT_POLICY_F32M: return launch_policy_1w<K, ACT_POLICY_F32M>(h, a);
+    case ACT_POLICY_F16: return launch_rollout_pair<K, FMT_F16>(h, a);
+    }
+    return rmav_fail(RMAV_ERR_INVALID, "unknown policy mode %d", kmode);
+}
+
+}  // namespace
+
+int rmav_launch_policy_rollout(rmav_handle h, int kmode, const RolloutArgs &a) {
+    switch (h->kind) {
+    case RMAV_QUAD2D: return launch_policy_k<QUAD2D>(h, kmode, a);
+    case RMAV_QUAD2D_SL: return launch_policy_k<QUAD2D_SL>(h, kmode, a);
+    case RMAV_QUAD3D: return launch_policy_k<QUAD3D>(h, kmode, a);
+    case RMAV_QUAD3D_SL: return launch_policy_k<QUAD3D_SL>(h, kmode, a);
+    case RMAV_REINMAV: return launch_policy_k<REINMAV>(h, kmode, a);
+    }
+    return rmav_fail(RMAV_ERR_INVALID, "bad kind");
+}

@@ -110,6 +110,40 @@ __device__ __forceinline__ void scale_biases_for_tanh() {
         lds_w[(q >> 7) * MfmaLayout::NET + MfmaLayout::B1 + (q & 127)] *= kTanhScale;
 }
 
+// Value of lane l ^ 32 - WITHOUT ds_bpermute.  v_permlane32_swap (gfx950) exchanges the upper half of one register with the
+// lower half of another inside the vector ALU: two instructions per value and no trip through the LDS crossbar (~50+ cycles).
+// It is also a correctness matter here (profiles/r04/mfma_bpermute_hazard.md): with __shfl_xor (= ds_bpermute_b32) behind the
+// MFMA chain and more than one MFMA-issuing wavefront per SIMD, a vector instruction that overwrote the B fragment of an
+// already executed v_mfma_f32_32x32x16 was followed, four instructions later, by a read that still returned the OLD register
+// contents in lanes 48..63 (the last quarter the LDS return path writes): ~10 of 1 024 wavefronts per 32-step rollout with two
+// (actor, critic) pairs per workgroup, ~1 per rollout for round 3's one-wavefront kernel at 262 144 envs, never with one
+// wavefront per SIMD.  Neither hipcc's wait states nor a dependent read of the last MFMA's last register removed it; taking
+// the LDS instruction out of the matrix-core kernels did (0 in 40 rollouts), and tests/test_gpu_ppo.py::
+// test_matrix_core_actors_are_deterministic repeats every variant at 2-4 wavefronts per SIMD.
+__device__ __forceinline__ float xor32(float v) {
+    const uint32_t x = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0]: the low half in both halves, r[1]: the high half
+    return __builtin_bit_cast(float, (threadIdx.x & 32u) ? r[0] : r[1]);
+}
+// sum over the wavefront, valid in lane 0; same additions in the same order as wave_sum (rmav_kernels.hpp), with the 32-lane
+// step on v_permlane32_swap and the rest on DPP row / bank shifts - no LDS instruction
+template <typename T> __device__ __forceinline__ T wave_sum_x(T v) {
+    v += __builtin_bit_cast(T, xor32(__builtin_bit_cast(float, v)));
+    {   // lane l += lane l + 16: row_bcast / permlane16 are not what we need; swap the 16-lane rows inside each 32-lane half
+        const uint32_t x = __builtin_bit_cast(uint32_t, v);
+        const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);   // r[0]: even rows duplicated, r[1]: odd rows duplicated
+        v += __builtin_bit_cast(T, (threadIdx.x & 16u) ? r[0] : r[1]);
+    }
+    // lane l += lane l + 8, 4, 2, 1 inside its 16-lane row: DPP row_shl (0x100 + n), in the vector ALU
+#define RMAV_DPP_ADD(CTRL) v += __builtin_bit_cast(T, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true))
+    RMAV_DPP_ADD(0x108);
+    RMAV_DPP_ADD(0x104);
+    RMAV_DPP_ADD(0x102);
+    RMAV_DPP_ADD(0x101);
+#undef RMAV_DPP_ADD
+    return v;
+}
+
 // One net (weights at float offset `net` of lds_w) for the two column tiles of this wavefront.
 // b_in0 / b_in1: layer-1 B fragments of the two column tiles.  Returns the first 4 output rows of each
 // column tile (valid in lanes with h == 0).
@@ -185,7 +219,7 @@ __device__ __forceinline__ void policy_forward_mfma(const float (&x)[16], float 
         const uint32_t lo = __builtin_bit_cast(uint32_t, x[j]), hi = __builtin_bit_cast(uint32_t, x[8 + j]);
         const float mine = kTanhScale * __builtin_bit_cast(float, (hi & hmask) | (lo & ~hmask));        // x[8h + j]
         const float send = kTanhScale * __builtin_bit_cast(float, (lo & hmask) | (hi & ~hmask));        // x[8(1-h) + j]: what the partner's fragment needs
-        const float recv = __shfl_xor(send, 32, 64);
+        const float recv = xor32(send);
         own[j] = (__bf16)mine;
         other[j] = (__bf16)recv;
     }
@@ -196,10 +230,10 @@ __device__ __forceinline__ void policy_forward_mfma(const float (&x)[16], float 
     // results sit in the h == 0 lanes: tile 0 is already home, tile 1 goes to the partner lane
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float from_partner = __shfl_xor(m.t1[r], 32, 64);
+        const float from_partner = xor32(m.t1[r]);
         mean[r] = h ? from_partner : m.t0[r];
     }
-    const float vp = __shfl_xor(v.t1[0], 32, 64);
+    const float vp = xor32(v.t1[0]);
     value = h ? vp : v.t0[0];
 }
 

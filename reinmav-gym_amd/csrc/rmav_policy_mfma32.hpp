@@ -123,7 +123,7 @@ __device__ __noinline__ float4 mlp_mfma32(Mfma32In bin, uint32_t net) {
     float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-        const float other = __shfl_xor(p[o], 32, 64);
+        const float other = xor32(p[o]);   // not ds_bpermute: rmav_policy_mfma.hpp
         const float lo = h ? other : p[o], hi = h ? p[o] : other;
         out[o] = (lo + hi) + w[L::B3 + o];
     }

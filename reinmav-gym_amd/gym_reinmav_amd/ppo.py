@@ -191,13 +191,17 @@ class _PolicyPacker:
     built once (NumPy, host) and every repack is: one ``cat`` of the parameters, one gather, and for the
     bf16 fragments one dtype conversion - a handful of launches, cheap enough to run before every rollout."""
 
-    def __init__(self, policy: MlpPolicy, n_obs: int, bf16_mfma: bool, f32_mfma: bool = False):
+    K_TANH = 2.8853900817779268   # 2 log2(e): the f16 actor's layer-2 fragments carry -2 k W2, layer 3's -2 W3 (include/rmav.h)
+
+    def __init__(self, policy: MlpPolicy, n_obs: int, bf16_mfma: bool, f32_mfma: bool = False, f16_mfma: bool = False):
         import numpy as np
 
         H = policy.pi[0].out_features
         assert H == 64 and policy.pi[1].in_features == 64, "the in-kernel policy is the 2 x 64 baselines mlp"
         assert n_obs <= 16
-        self.policy, self.bf16, self.f32m = policy, bool(bf16_mfma), bool(f32_mfma)
+        # f16: the bf16 fragment layout with f16 pairs (and the tanh fold's weight scales)
+        self.f16 = bool(f16_mfma)
+        self.policy, self.bf16, self.f32m = policy, bool(bf16_mfma) or self.f16, bool(f32_mfma)
         assert not (self.bf16 and self.f32m)
         self.params = [policy.pi[0].weight, policy.pi[0].bias, policy.pi[1].weight, policy.pi[1].bias,
                        policy.pi[2].weight, policy.pi[2].bias, policy.vf[0].weight, policy.vf[0].bias,
@@ -269,6 +273,9 @@ class _PolicyPacker:
             self.n_frag = len(frag[0]) // 2        # floats per net of fragments (2 bf16 per float)
             self.n_bias = len(f32[0])
             self.n_out = 2 * (self.n_frag + self.n_bias) + 4
+            if self.f16:   # per fragment element: 1 (layer 1), -2k (layer 2), -2 (layer 3)
+                per_net = [1.0] * (2 * 64 * 8) + [-2.0 * self.K_TANH] * (8 * 64 * 8) + [-2.0] * (4 * 64 * 8)
+                self.frag_scale = torch.tensor(per_net + per_net, dtype=torch.float32, device=dev)
 
     def native_maps(self):
         """(idx_lo, idx_hi) int32 device tensors of ``rmav_pack_policy``: output word i = flat[idx_lo[i]] (idx_hi[i] < 0) or the
@@ -300,8 +307,8 @@ class _PolicyPacker:
         n = len(ps)
         ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in ps])
         sizes = (C.c_int64 * n)(*[p.numel() for p in ps])
-        A.check(A.lib().rmav_pack_policy(env._h, n, ptrs, sizes, C.c_void_p(lo.data_ptr()), C.c_void_p(hi.data_ptr()), self.n_out,
-                                         C.c_void_p(out.data_ptr())))
+        fn = A.lib().rmav_pack_policy_f16 if self.f16 else A.lib().rmav_pack_policy
+        A.check(fn(env._h, n, ptrs, sizes, C.c_void_p(lo.data_ptr()), C.c_void_p(hi.data_ptr()), self.n_out, C.c_void_p(out.data_ptr())))
         return out
 
     def pack(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -310,7 +317,10 @@ class _PolicyPacker:
             if self.f32m or not self.bf16:
                 res = flat[self.idx_f32]
             else:
-                fr = flat[self.idx_frag].to(torch.bfloat16).view(torch.int16).view(torch.float32)   # [2 * n_frag]
+                if self.f16:
+                    fr = (flat[self.idx_frag] * self.frag_scale).to(torch.float16).view(torch.int16).view(torch.float32)
+                else:
+                    fr = flat[self.idx_frag].to(torch.bfloat16).view(torch.int16).view(torch.float32)   # [2 * n_frag]
                 bi = flat[self.idx_bias]
                 res = torch.cat([fr[:self.n_frag], bi[:self.n_bias], fr[self.n_frag:], bi[self.n_bias:2 * self.n_bias],
                                  bi[2 * self.n_bias:]])
@@ -337,26 +347,34 @@ def pack_policy_weights_bf16(policy: MlpPolicy, n_obs: int, out: Optional[torch.
     return _PolicyPacker(policy, n_obs, True).pack(out)
 
 
+def pack_policy_weights_f16(policy: MlpPolicy, n_obs: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """f16 MFMA fragments in the bf16 layout, layers 2 / 3 pre-scaled by -2 * 2 log2(e) / -2 (tanh folded into the next
+    layer: the kernel hands (1 - tanh z) / 2 on and derives the matching biases from these rounded weights)."""
+    return _PolicyPacker(policy, n_obs, False, f16_mfma=True).pack(out)
+
+
 class FusedPolicyCollector:
     """Same buffers and semantics as :class:`RolloutCollector`, but ONE kernel launch per rollout: the policy
     (2 x 64 tanh MLP + value net, weights staged in LDS) is evaluated inside the rollout kernel by the lane
     that owns the env (``rmav_rollout_policy``), so nothing but the trajectory touches HBM."""
 
     def __init__(self, env: BatchedQuadrotor, policy: MlpPolicy, nsteps: int, bf16_mfma: bool = False,
-                 f32_mfma: Optional[bool] = None, native_pack: bool = True):
+                 f32_mfma: Optional[bool] = None, native_pack: bool = True, f16_mfma: bool = False):
         """Actor arithmetic: fp32 on the fp32-input matrix instructions (``v_mfma_f32_32x32x2_f32``; the default),
         ``f32_mfma=False`` fp32 FMAs on the vector ALU (same precision class - only the summation order differs - at
-        half the speed), ``bf16_mfma=True`` bf16 operands on the matrix cores (2.5x faster again, ~1e-2 on means)."""
+        half the speed), ``bf16_mfma=True`` bf16 operands on the matrix cores (~1e-2 on means), ``f16_mfma=True`` f16
+        operands with tanh folded into the next layer (the fastest, ~1e-3 on means; csrc/rmav_policy_pair.hpp)."""
         import ctypes as C
 
+        assert not (bf16_mfma and f16_mfma)
         if f32_mfma is None:
-            f32_mfma = not bf16_mfma
+            f32_mfma = not (bf16_mfma or f16_mfma)
 
         from . import _abi as A
 
         assert env.auto_reset, "rollouts need VecEnv semantics (auto-reset)"
         self.env, self.policy, self.T = env, policy, int(nsteps)
-        self.bf16_mfma, self.f32_mfma = bool(bf16_mfma), bool(f32_mfma)
+        self.bf16_mfma, self.f32_mfma, self.f16_mfma = bool(bf16_mfma), bool(f32_mfma), bool(f16_mfma)
         self._C, self._A = C, A
         dev = torch.device("cuda", env.device)
         N, nS, nA, T = env.num_envs, env.nS, env.nA, self.T
@@ -367,11 +385,11 @@ class FusedPolicyCollector:
         self.val = torch.empty((T + 1, N), **f32)
         self.rew = torch.empty((T, N), **f32)
         self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
-        n_w = (A.lib().rmav_policy_weight_count_bf16() if self.bf16_mfma else
+        n_w = (A.lib().rmav_policy_weight_count_bf16() if (self.bf16_mfma or self.f16_mfma) else
                A.lib().rmav_policy_weight_count_f32_mfma() if self.f32_mfma else A.lib().rmav_policy_weight_count(env.kind))
         self.weights = torch.empty(n_w, **f32)
         assert self.weights.data_ptr() % 16 == 0
-        self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma, f32_mfma=self.f32_mfma)
+        self._packer = _PolicyPacker(policy, env.nS, self.bf16_mfma, f32_mfma=self.f32_mfma, f16_mfma=self.f16_mfma)
         assert self._packer.n_out == n_w, (self._packer.n_out, n_w)
         self.obs[0].copy_(env.get_state(layout="soa", device_out=True))
         # The weight repack before every rollout: one gather launch behind the C ABI (rmav_pack_policy).  As ~8 dependent torch
@@ -379,9 +397,11 @@ class FusedPolicyCollector:
         # hipGraph of those launches replayed no faster (the dependent-launch floor, not the host, is what they cost).
         self.native_pack = bool(native_pack)
         p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
-        self._call = (A.lib().rmav_rollout_policy, env._h, self.T, p(self.weights), p(self.act), p(self.obs[1:]), p(self.rew), p(self.done),
+        # (the env's handle is read at call time: env.close() clears it, and a cached copy would hand a freed handle to the library)
+        self._call = (A.lib().rmav_rollout_policy, self.T, p(self.weights), p(self.act), p(self.obs[1:]), p(self.rew), p(self.done),
                       p(self.logp), p(self.val),
-                      A.POLICY_BF16_MFMA if self.bf16_mfma else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32)
+                      A.POLICY_F16_MFMA if self.f16_mfma else A.POLICY_BF16_MFMA if self.bf16_mfma
+                      else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32)
 
     def _pack(self):
         if self.native_pack:
@@ -390,9 +410,11 @@ class FusedPolicyCollector:
             self._packer.pack(out=self.weights)
 
     def collect(self):
+        if self.env._h is None:
+            raise self._A.RmavError(self._A.ERR_INVALID, "the env of this collector is closed")
         self._pack()
         fn = self._call[0]
-        self._A.check(fn(*self._call[1:]))
+        self._A.check(fn(self.env._h, *self._call[1:]))
         return self
 
     def roll_over(self):

@@ -71,8 +71,36 @@ def test_fp32_mfma_actor_leaves_room_for_two_wavefronts_per_simd(usage):
         assert u["vgpr"] + u["agpr"] <= 256 and u["spill"] == 0, (kind, u)
 
 
-def _kernel_asm(prefix):
-    path = os.path.join(PKG, "build", "rmav_abi.gfx950.s")
+def test_pair_actors_fit_two_wavefronts_per_simd(usage):
+    """k_rollout_pair<K, FMT_BF16 | FMT_F16>: at BASELINE's C5 shape every SIMD hosts two of these wavefronts: <= 256 registers."""
+    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav14k_rollout_pairILi")}
+    assert len(hits) == 10
+    for n, u in hits.items():
+        assert u["vgpr"] + u["agpr"] <= 256 and u["spill"] == 0 and u["scratch"] == 0 and u["occ"] >= 2, (n, u)
+
+
+def test_matrix_core_kernels_have_no_lds_permutes_and_no_compiler_packed_fp32():
+    """The policy-in-kernel rollouts are built without the SLP vectoriser and exchange lanes with v_permlane32_swap
+    (csrc/rmav_policy_abi.hip, csrc/rmav_policy_mfma.hpp: two measured sources of stale register reads in lanes 48..63 when
+    several MFMA-issuing wavefronts share a SIMD).  The hand-written packed operations of the activations are
+    v_pk_add_f32 / v_pk_fma_f32 with scalar constants; v_pk_mul_f32 / v_pk_mov_b32 only ever came from the vectoriser."""
+    subprocess.run(["make", "-s", "-C", PKG, "asm"], check=True)
+    txt = open(os.path.join(PKG, "build", "rmav_policy_abi.gfx950.s")).read()
+    bodies = re.split(r"^(_ZN4rmav\w+):[^\n]*\n", txt, flags=re.M)   # [pre, name, body, name, body, ...]
+    seen = 0
+    for name, body in zip(bodies[1::2], bodies[2::2]):
+        body = body.split(".Lfunc_end")[0]
+        if "v_mfma" not in body and not re.match(r"_ZN4rmav9k_rolloutILi\dELi[48]E", name):
+            continue                                  # (the fp32 vector-ALU actor: no matrix instructions)
+        seen += 1
+        for bad in ("ds_bpermute", "ds_permute", "v_pk_mul_f32", "v_pk_mov_b32"):
+            assert bad not in body, (name, bad)
+    assert seen >= 21, seen   # 10 pair kernels, 5 + 5 one-wavefront bf16 / fp32-MFMA kernels, mlp_mfma
+    assert txt.count("v_permlane32_swap") >= 100 and txt.count("v_mfma_f32_32x32x16_f16") >= 100
+
+
+def _kernel_asm(prefix, which="rmav_abi"):
+    path = os.path.join(PKG, "build", which + ".gfx950.s")
     out, on = [], False
     for line in open(path):
         if not on and line.startswith(prefix):
