@@ -731,11 +731,18 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
 
     out = {"workload": f"{ENV_ID[kind]}, {n} envs x {T}-step rollouts, 2x64 tanh MLP policy + value net in-kernel, "
                        "trajectory + logp + values written to HBM; then rmav_gae over the [T][N] result"}
-    for actor in ("fp32_valu", "fp32_mfma", "bf16_mfma"):
+    # instructions per 64 envs and env-step by class, measured with SQ counters (tools/profile_actors.sh -> profiles/actor_instr_mix.json),
+    # priced with the per-class vector-pipe cycles of tools/micro/issue_rate.hip (profiles/r04/issue_rate.md): the roofline that binds
+    mix_path = os.path.join(ROOT, "profiles", "actor_instr_mix.json")
+    mix = json.load(open(mix_path)) if os.path.exists(mix_path) else {}
+    # bf16_1w: round 3's kernel (one wavefront per 64 envs); bf16_mfma / f16_mfma: (actor, critic) wavefront pairs (rmav_policy_pair.hpp)
+    for actor in ("fp32_valu", "fp32_mfma", "bf16_1w", "bf16_mfma", "f16_mfma"):
         torch.manual_seed(0)
         env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        if actor == "bf16_1w":
+            env.set_tuning(policy_pair=0)
         pol = MlpPolicy(env.nS, env.nA).to(dev)
-        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=(actor == "bf16_mfma"), f32_mfma=(actor == "fp32_mfma"))
+        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f32_mfma=(actor == "fp32_mfma"), f16_mfma=(actor == "f16_mfma"))
         adv, ret = torch.empty_like(ro.rew), torch.empty_like(ro.rew)
         sums = torch.zeros(2, dtype=torch.float64, device=dev)
         for _ in range(5):
@@ -755,7 +762,7 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
         e3, e4 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         C_, A_ = ro._C, ro._A
         pp = lambda t: C_.c_void_p(t.data_ptr())  # noqa: E731
-        prec = A_.POLICY_BF16_MFMA if actor == "bf16_mfma" else A_.POLICY_FP32_MFMA if actor == "fp32_mfma" else A_.POLICY_FP32
+        prec = ro._call[-1]
         e3.record()
         for _ in range(iters):
             A_.check(A_.lib().rmav_rollout_policy(env._h, T, pp(ro.weights), pp(ro.act), pp(ro.obs[1:]), pp(ro.rew), pp(ro.done),
@@ -772,8 +779,9 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
         if actor != "fp32_valu":
             # matrix-pipe work incl. tile padding: bf16 = 56 v_mfma_f32_32x32x16_bf16 per 64 envs and step (inputs padded 10 -> 16,
             # outputs 4 / 1 -> 32); fp32 = 2 nets x (2 ceil(nS / 2) + 64) v_mfma_f32_32x32x2_f32 per 32 envs (layer 3 on the vector ALU)
-            padded = 56 * 2 * 32 * 32 * 16 / 64 if actor == "bf16_mfma" else 2 * (2 * ((nS + 1) // 2) + 64) * 2 * 32 * 32 * 2 / 32
-            peak = 2500.0 if actor == "bf16_mfma" else 157.3   # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
+            half = actor != "fp32_mfma"                          # bf16 / f16 operands: the same instruction count and peak
+            padded = 56 * 2 * 32 * 32 * 16 / 64 if half else 2 * (2 * ((nS + 1) // 2) + 64) * 2 * 32 * 32 * 2 / 32
+            peak = 2500.0 if half else 157.3   # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
             ach = padded * n * T / (ms_k * 1e-3) / 1e12
             roof["mfma"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                             "flops_per_env_step_incl_tile_padding": padded, "useful_flops_per_env_step": useful,
@@ -782,7 +790,25 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
             ach = useful * n * T / (ms_k * 1e-3) / 1e12
             roof["valu"] = {"bound": "valu_fp32", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3,
                             "useful_flops_per_env_step": useful}
-        out[actor] = {"ms_per_rollout_incl_weight_pack": ms_ro, "ms_per_rollout_kernel": ms_k,
+        m = mix.get(actor)
+        if m:   # SIMD-cycles the launch had per 64 envs and env-step vs the cycles its measured instruction mix needs on the vector pipe
+            sclk_ghz = float(m.get("clock_ghz", 2.2))   # GRBM_GUI_ACTIVE / kernel time of that actor's profiled launches
+            avail = ms_k * 1e-3 * sclk_ghz * 1e9 * 1024 / (n / 64 * T)
+            other = m["valu"] - m["trans"] - m["cvt"] - m["mfma"] - m["packed_static"]
+            need = ((m["trans"] * 8.8 + (m["valu"] - m["trans"] - m["mfma"]) * 5.3) if m["lone_wavefront"] else
+                    (m["trans"] * 8.4 + m["cvt"] * 4.45 + m["packed_static"] * 5.0 + other * 2.8))
+            roof["valu_pipe"] = {"bound": "valu_issue" if m["lone_wavefront"] else "valu_pipe", "frac": need / avail,
+                                 "needed_simd_cycles_per_64_env_steps": need, "available_simd_cycles_per_64_env_steps": avail,
+                                 "shader_clock_GHz": sclk_ghz,
+                                 "instructions_per_64_env_steps": {k: m[k] for k in ("valu", "trans", "cvt", "mfma", "salu", "lds", "vmem_wr", "packed_static")},
+                                 "cycles_per_instruction": ({"transcendental": 8.8, "other": 5.3, "note": "ONE wavefront per SIMD: its issue rate"}
+                                                            if m["lone_wavefront"] else
+                                                            {"transcendental": 8.4, "convert": 4.45, "packed_f32": 5.0, "other": 2.8,
+                                                             "note": "two wavefronts per SIMD: the vector pipe's occupancy"}),
+                                 "source": "SQ counters (profiles/r04/actors_sq.md) x tools/micro/issue_rate.hip (profiles/r04/issue_rate.md)"}
+        binding = max(roof, key=lambda k: roof[k]["frac"])
+        out[actor] = {"bound": roof[binding]["bound"], "bound_frac": roof[binding]["frac"],
+                      "ms_per_rollout_incl_weight_pack": ms_ro, "ms_per_rollout_kernel": ms_k,
                       "env_steps_per_s": n * T / (ms_ro * 1e-3), "kernel_env_steps_per_s": n * T / (ms_k * 1e-3),
                       "gae_ms": ms_gae, "gae_GBps": 17.0 * n * T / (ms_gae * 1e-3) / 1e9, "roofline": roof}
         env.close()

@@ -40,7 +40,9 @@ template <int K, int FMT> int launch_rollout_pair(rmav_handle h, const RolloutAr
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     const int forced = h->tune[RMAV_TUNE_PAIR_GROUP];
-    const int g = (forced >= 1 && forced <= kPairGroupMax) ? forced : kPairGroupDefault;
+    // measured (profiles/r04/actor_bench.txt, quadrotor3d x 32 steps): 65 536 envs 4 pairs 15.0 G env-steps/s, 2 pairs 14.1, 1 pair 13.7
+    // (one workgroup per CU, weights staged once per CU); 131 072 envs 2 pairs 15.8 - 16.7, 4 pairs 15.5 - 16.3, 1 pair 11.1
+    const int g = (forced >= 1 && forced <= kPairGroupMax) ? forced : (h->n <= 98304 ? 4 : 2);
     const int64_t per_wg = 64 * g;
     hipLaunchKernelGGL((k_rollout_pair<K, FMT>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g), pair_lds_bytes<K>(g),
                        h->stream, a, p, pc);

@@ -37,7 +37,6 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 
 constexpr int kPairGroupMax = 4;   // (actor, critic) pairs per workgroup: 1 .. 4 (512 threads), a launch parameter
-constexpr int kPairGroupDefault = 2;
 
 template <int FMT> struct PairOps;
 template <> struct PairOps<FMT_BF16> {

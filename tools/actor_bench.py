@@ -9,7 +9,7 @@ import gym_reinmav_amd as g
 from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
 
 kind, T, iters = os.environ.get("KIND", "quad3d"), int(os.environ.get("T", "32")), int(os.environ.get("ITERS", "60"))
-variants = [("fp32_mfma", {}), ("bf16_1w", {"policy_pair": 0})] + [(a, {"pair_group": G}) for a in ("bf16", "f16") for G in (1, 2, 4)]
+variants = [("fp32_valu", {}), ("fp32_mfma", {}), ("bf16_1w", {"policy_pair": 0})] + [(a, {"pair_group": G}) for a in ("bf16", "f16") for G in (1, 2, 4)]
 if os.environ.get("VARIANTS"):
     variants = [v for v in variants if v[0] in os.environ["VARIANTS"].split(",")]
 for n in [int(x) for x in os.environ.get("N", "65536").split(",")]:
