@@ -313,14 +313,19 @@ def main():
             # the collective behind the C ABI (RCCL from librmav's own stream, ~15 us of host time per post); every rank must
             # take the same path, so fall back together to the torch.distributed exchange if any rank cannot set it up
             ok = 0
-            if not gloo and os.environ.get("RMAV_BENCH_EXCHANGE", "native") == "native":
+            # (test hook: RMAV_BENCH_RCCL_LIB = a stand-in for librccl.so.1 that lets rank processes share ONE GPU - tests/stub_rccl -
+            #  handed to the library with rmav_comm_use_library; the native exchange then runs under the gloo process group too)
+            rccl_lib = os.environ.get("RMAV_BENCH_RCCL_LIB", "")
+            if rccl_lib:
+                A.check(A.lib().rmav_comm_use_library(rccl_lib.encode()))
+            if (not gloo or rccl_lib) and os.environ.get("RMAV_BENCH_EXCHANGE", "native") == "native":
                 try:   # communicator + one whole exchange under a watchdog: a rank that is stuck falls back with the others
                     exchange = NativeStatsExchange(env, n_total, connect_timeout_s=float(os.environ.get("RMAV_BENCH_CONNECT_TIMEOUT", "90")))
                     ok = 1
                 except BaseException as e:  # pragma: no cover
                     print(f"[rank {rank}] native exchange unavailable: {e!r}", file=sys.stderr)
                     native_abandoned = isinstance(e, TimeoutError)
-                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cpu" if gloo else dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 ok = int(flag.item())
             if ok:
@@ -330,6 +335,8 @@ def main():
                     exchange.close()
                 exchange = EpisodeStatsExchange(n_total, "cpu" if gloo else dev)
                 exchange_kind = "torch.distributed all_gather_into_tensor (" + dist.get_backend() + "), second stream"
+        # the exchange takes host tensors only when it is torch.distributed's over gloo (ranks sharing a GPU without the stand-in)
+        host_xchg = gloo and not isinstance(exchange, NativeStatsExchange)
 
         # step mode: ring of pre-generated action buffers (fresh random actions every launch).  64 buffers = 67 MB at
         # 65 536 envs: like the actions a policy kernel has just written, they are still on chip (L2 / Infinity Cache)
@@ -367,7 +374,7 @@ def main():
                     for b in ring:
                         b["actions"].uniform_(lo, hi)
 
-                arm = exchange is not None and not gloo and os.environ.get("RMAV_BENCH_ARM", "1") == "1"
+                arm = exchange is not None and not host_xchg and os.environ.get("RMAV_BENCH_ARM", "1") == "1"
 
                 def run(k):
                     for _ in range(k):
@@ -382,7 +389,7 @@ def main():
                                         want=("actions", "obs", "rew", "done"), device_out=True, out=ring[it[0] % R])
                         it[0] += 1
                         if exchange is not None and it[0] % args.exchange_every == 0:   # the path's one exchange, once per rollout
-                            if gloo:
+                            if host_xchg:
                                 eb = env.episode_buffers()
                                 exchange.post(torch.from_numpy(eb["last_return"]), torch.from_numpy(eb["last_length"]))
                             else:
@@ -490,7 +497,7 @@ def main():
             during = [t.clone() for t in gathered] if gathered is not None else None   # the timed region's last exchange
             eb = env.episode_buffers(device_out=not gloo)
             mine = [torch.as_tensor(eb["last_return"]), torch.as_tensor(eb["last_length"])]
-            if gloo:
+            if host_xchg:
                 exchange.post(mine[0], mine[1])
             else:
                 exchange.post(env=env)

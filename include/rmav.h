@@ -325,9 +325,19 @@ int rmav_normalize(rmav_handle h, float *x, int64_t count, float mean, float rst
  * other ranks out of band (file, MPI, a torch store ...); every rank then calls rmav_comm_create. */
 typedef struct rmav_comm_s *rmav_comm;
 #define RMAV_COMM_ID_BYTES 128
+/* Optional, before any other rmav_comm_* call of the process: resolve the five collective entry points (ncclGetUniqueId,
+ * ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString) from THIS shared object instead of librccl.so.1 - a
+ * site's own RCCL build, or the test suite's stand-in that lets two rank processes share ONE GPU (tests/stub_rccl). */
+int rmav_comm_use_library(const char *path);
 int rmav_comm_unique_id(void *id_out /* RMAV_COMM_ID_BYTES bytes, host */);
 int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device);
 int rmav_comm_destroy(rmav_comm c);
+/* One tiny all-gather on the communicator's own stream, awaited on the HOST for at most timeout_s seconds (< 0: no limit):
+ * RMAV_OK, or RMAV_ERR_TIMEOUT.  RCCL connects its transports inside the FIRST collective's enqueue - a host-side exchange
+ * with the peers that blocks when one of them is gone - so a caller that wants a bounded set-up runs rmav_comm_create +
+ * rmav_comm_warmup on a helper thread and joins it with a deadline (gym_reinmav_amd.distributed.NativeStatsExchange does);
+ * no handle and no handle's stream is involved. */
+int rmav_comm_warmup(rmav_comm c, double timeout_s);
 /* returns_out f32 [n_total], lengths_out i32 [n_total] (DEVICE pointers) <- return / length of every env's most
  * recently finished episode, in global env order, on every rank.  Enqueued on the handle's stream (pack ->
  * ncclAllGather over xGMI -> unpack); does not synchronise.  Needs RMAV_F_TRACK_EPISODES. */
@@ -346,8 +356,12 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
  * same result.  Only a call that is ONE fused launch over all of the handle's envs takes the snapshot; if none happens
  * between _arm and _post (single-step launches incl. rmav_rollout(fused = 0), a sliced launch), or if another stepping
  * launch follows the one that took it, _post packs as usual.  The communicator stream's wait for the armed launch is
- * bounded (2 s): past that, _post / _result / _wait return RMAV_ERR_TIMEOUT.  One armed exchange per handle at a time;
- * _post with the same communicator consumes it; destroying the communicator disarms the handle. */
+ * bounded: 2 s counted from the moment that launch BEGINS on the device (it may sit behind any amount of queued work first).
+ * Past that the waiter poisons this rank's payload - return NaN, length -1 for each of its envs, on every rank - and the
+ * collective is issued all the same, so no peer hangs; rmav_allgather_stats_wait (and _result, once the waiter has run)
+ * return RMAV_ERR_TIMEOUT for THAT post only: later posts on the communicator are unaffected.  One armed exchange per handle
+ * and per communicator at a time; _post with the same communicator consumes it; destroying the communicator or the handle
+ * disarms the other. */
 int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total);
 int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
 /* HOST-side bounded wait for the most recently posted exchange (polls its completion event; touches no stream):

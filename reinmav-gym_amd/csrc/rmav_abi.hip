@@ -195,8 +195,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h), dim3(block_size(h)), lds, h->stream, a, p, pc);
     }
-    HIP_TRY(hipGetLastError());
-    return RMAV_OK;
+    return check_rollout_launch(h, a);
 }
 
 // RMAV_TUNE_SPLIT = 0 | 1 overrides the rule.
@@ -1176,14 +1175,19 @@ struct RcclApi {
 };
 // resolved on first use: librmav.so has no link-time dependency on RCCL, and a process that already loaded
 // librccl.so.1 (torch does) shares that copy
+char g_rccl_path[1024] = "";   // rmav_comm_use_library
+bool g_rccl_tried = false;
 RcclApi *rccl() {
     static RcclApi api;
-    static bool tried = false;
-    if (!tried) {
-        tried = true;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (api.lib) break;
+    if (!g_rccl_tried) {
+        g_rccl_tried = true;
+        if (g_rccl_path[0]) {
+            api.lib = dlopen(g_rccl_path, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+                if (api.lib) break;
+            }
         }
         if (api.lib) {
             api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
@@ -1204,6 +1208,13 @@ constexpr uint32_t kCommMagic = 0x524d4143u;  // 'RMAC'
             return rmav_fail(RMAV_ERR_HIP, "%s failed: %s", #expr, R->GetErrorString ? R->GetErrorString(r_) : "RCCL error"); \
     } while (0)
 }  // namespace
+
+int rmav_comm_use_library(const char *path) {
+    if (g_rccl_tried) return rmav_fail(RMAV_ERR_INVALID, "the collective library has already been loaded: call this before any other rmav_comm_* function");
+    if (!path || !path[0] || strlen(path) >= sizeof(g_rccl_path)) return rmav_fail(RMAV_ERR_INVALID, "path is NULL, empty or too long");
+    snprintf(g_rccl_path, sizeof(g_rccl_path), "%s", path);
+    return RMAV_OK;
+}
 
 int rmav_comm_unique_id(void *id_out) {
     if (!id_out) return rmav_fail(RMAV_ERR_INVALID, "id_out is NULL");
@@ -1255,12 +1266,14 @@ int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int de
         e = hipEventCreateWithFlags(&c->ready[k], evf);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->done[k], evf);
     }
-    // the word k_wait_arrivals raises when it gives up on an armed launch (pinned host memory: the host reads it for free)
-    if (e == hipSuccess) e = hipHostMalloc((void **)&c->timeout_flag, sizeof(uint32_t), hipHostMallocMapped);
+    // the words k_wait_arrivals writes when it gives up on an armed launch (pinned host memory: the host reads them for free)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->timeout_seq, kExchangeDepth * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess) {
-        *c->timeout_flag = 0;
-        e = hipHostGetDevicePointer((void **)&c->timeout_flag_dev, c->timeout_flag, 0);
+        memset(c->timeout_seq, 0, kExchangeDepth * sizeof(uint32_t));
+        e = hipHostGetDevicePointer((void **)&c->timeout_seq_dev, c->timeout_seq, 0);
     }
+    if (e == hipSuccess) e = hipMalloc((void **)&c->started, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(c->started, 0, sizeof(uint32_t));
     if (e != hipSuccess) {
         (void)hipGetLastError();
         (void)rmav_comm_destroy(c);
@@ -1298,7 +1311,8 @@ int rmav_comm_destroy(rmav_comm c) {
     }
     if (c->flag) (void)hipFree(c->flag);
     if (c->arrive) (void)hipFree(c->arrive);
-    if (c->timeout_flag) (void)hipHostFree(c->timeout_flag);
+    if (c->timeout_seq) (void)hipHostFree(c->timeout_seq);
+    if (c->started) (void)hipFree(c->started);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->armed_by && c->armed_by->magic == kMagic && c->armed_by->xchg.comm == c) {
         // a handle still points at this communicator: disarm it, or its next rollout would dereference freed memory
@@ -1308,6 +1322,52 @@ int rmav_comm_destroy(rmav_comm c) {
     c->magic = 0;
     delete c;
     return RMAV_OK;
+}
+
+int rmav_comm_warmup(rmav_comm c, double timeout_s) {
+    if (!c || c->magic != kCommMagic) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    RcclApi *R = rccl();
+    if (!R) return rmav_fail(RMAV_ERR_NO_DEVICE, "librccl.so.1 could not be loaded");
+    DeviceGuard guard(c->device);
+    int32_t *buf = nullptr;   // [1 + world]: this rank's word, then the gathered words
+    HIP_TRY(hipMalloc((void **)&buf, sizeof(int32_t) * (size_t)(1 + c->world)));
+    hipEvent_t ev = nullptr;
+    hipError_t e = hipMemsetAsync(buf, 0, sizeof(int32_t) * (size_t)(1 + c->world), c->stream);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    int rc = RMAV_OK;
+    if (e != hipSuccess) {
+        rc = rmav_fail(RMAV_ERR_HIP, "rmav_comm_warmup: %s", hipGetErrorString(e));
+    } else {
+        // RCCL connects its transports inside the first collective's enqueue (a host-side exchange with the peers): this is the
+        // call that may block when a peer is gone, and it touches no handle's stream
+        const ncclResult_t r = R->AllGather(buf, buf + 1, 1, ncclInt32, c->comm, c->stream);
+        if (r != ncclSuccess) rc = rmav_fail(RMAV_ERR_HIP, "ncclAllGather failed: %s", R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+    }
+    if (rc == RMAV_OK && hipEventRecord(ev, c->stream) != hipSuccess) rc = rmav_fail(RMAV_ERR_HIP, "hipEventRecord failed");
+    if (rc == RMAV_OK) {
+        timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (;;) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipSuccess) break;
+            (void)hipGetLastError();
+            if (q != hipErrorNotReady) { rc = rmav_fail(RMAV_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(q)); break; }
+            timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if (timeout_s >= 0 && (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > timeout_s) {
+                rc = rmav_fail(RMAV_ERR_TIMEOUT, "the warm-up collective did not complete within %.3f s", timeout_s);
+                break;
+            }
+            timespec nap = {0, 50000};
+            nanosleep(&nap, nullptr);
+        }
+    }
+    // (on a time-out the collective may still be in flight: the buffer and the event are left to the process, not freed under it)
+    if (rc != RMAV_ERR_TIMEOUT) {
+        if (ev) (void)hipEventDestroy(ev);
+        (void)hipFree(buf);
+    }
+    return rc;
 }
 
 int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
@@ -1396,6 +1456,8 @@ int exchange_slot(rmav_handle h, rmav_comm c, int64_t n_total, int64_t *cmax_out
 int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total) {
     CHECK_HANDLE(h);
     if (h->xchg.armed) return rmav_fail(RMAV_ERR_INVALID, "an exchange is already armed on this handle: post it first");
+    if (c && c->magic == kCommMagic && c->armed_by && c->armed_by != h)
+        return rmav_fail(RMAV_ERR_INVALID, "this communicator is armed by another handle: post that exchange first");
     int64_t cmax = 0;
     int k = 0;
     if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) return rc;
@@ -1430,13 +1492,18 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
     } else if (int rc = exchange_slot(h, c, n_total, &cmax, &k)) {
         return rc;
     }
-    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an earlier armed exchange never saw its rollout launch complete");
-    if (armed && h->xchg.fired && !h->xchg.stale) {
+    // (the gather that last used this buffer pair has finished - exchange_slot waited for it - so its time-out word is history)
+    c->timeout_seq[k] = 0;
+    c->slot_seq[k] = (uint32_t)(c->posts + 1);
+    c->armed_slot[k] = armed && h->xchg.fired && !h->xchg.stale;
+    if (c->armed_slot[k]) {
         // the rollout launch itself wrote the snapshot and its wavefronts' arrival words: nothing enters the compute stream.
-        // The wait is bounded (kArrivalWaitTicks of the 100 MHz clock): if the armed launch never completes, the waiter raises
-        // timeout_flag and lets the gather go ahead, so the communicator's stream cannot hang for ever behind it.
+        // The wait is bounded (k_wait_arrivals: 2 s from the moment the armed launch begins): past that the waiter poisons this
+        // rank's payload, notes the post number in the pair's time-out word and lets the gather go ahead - the peers get their
+        // collective either way, and only THIS post reports RMAV_ERR_TIMEOUT.
         hipLaunchKernelGGL(k_wait_arrivals, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->arrive, h->xchg.expected,
-                           h->xchg.seq, kArrivalWaitTicks, c->timeout_flag_dev);
+                           h->xchg.seq, (const uint32_t *)c->started, kArrivalWaitTicks, kArrivalTotalTicks, c->timeout_seq_dev + k, c->send[k],
+                           cmax);
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
@@ -1465,8 +1532,11 @@ int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, flo
     if (int rc = check_shard(h, c, n_total, &cmax)) return rc;
     if (!returns_out || !lengths_out) return rmav_fail(RMAV_ERR_INVALID, "returns_out / lengths_out are required (device pointers)");
     if (c->posts == 0 || cmax != c->cmax) return rmav_fail(RMAV_ERR_INVALID, "no exchange of this size has been posted");
-    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
     const int k = (c->posts - 1) % c->depth;
+    // (known only if the waiter has already run; rmav_allgather_stats_wait knows for certain.  Either way the payload of a
+    // timed-out post is poisoned - return NaN, length -1 for this rank's envs - on every rank.)
+    if (c->armed_slot[k] && c->timeout_seq[k] == c->slot_seq[k])
+        return rmav_fail(RMAV_ERR_TIMEOUT, "the armed rollout launch of this exchange did not complete within 2 s of starting");
     HIP_TRY(hipStreamWaitEvent(h->stream, c->done[k], 0));
     hipLaunchKernelGGL(k_unpack_stats, dim3((unsigned)((n_total + 255) / 256)), dim3(256), 0, h->stream,
                        (const int32_t *)c->recv[k], n_total, (int32_t)c->world, cmax, returns_out, lengths_out);
@@ -1493,7 +1563,8 @@ int rmav_allgather_stats_wait(rmav_comm c, double timeout_s) {
         timespec nap = {0, 50000};
         nanosleep(&nap, nullptr);
     }
-    if (*c->timeout_flag) return rmav_fail(RMAV_ERR_TIMEOUT, "an armed exchange never saw its rollout launch complete");
+    if (c->armed_slot[k] && c->timeout_seq[k] == c->slot_seq[k])
+        return rmav_fail(RMAV_ERR_TIMEOUT, "the armed rollout launch of this exchange did not complete within 2 s of starting");
     return RMAV_OK;
 }
 

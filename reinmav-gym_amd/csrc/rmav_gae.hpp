@@ -198,20 +198,41 @@ __global__ void k_signal(uint32_t *flag, uint32_t seq) {
 // post's) in its arrival word: one workgroup polling `count` words with agent-scope loads.  hipStreamWaitValue32 is a
 // spinning one-wavefront kernel of the runtime as well (__amd_rocclr_streamOpsWait in the kernel trace); this one waits
 // for the rollout kernel's own wavefronts, so the compute stream needs no pack and no signal kernel.
-__global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, uint32_t count, uint32_t seq,
-                                                       unsigned long long max_ticks, uint32_t *timeout_flag) {
-    // Bounded: if the armed launch never publishes (its launch failed after the host armed it, or the device was reset under
-    // it), give up after max_ticks of the constant 100 MHz clock, raise *timeout_flag (pinned host memory: rmav_allgather_stats_*
-    // then return RMAV_ERR_TIMEOUT) and let the stream go on - a communicator stream that spins for ever would also block
-    // every other rank's collective.
+// Bounded, so that a communicator stream can never spin for ever (it would block every other rank's collective too):
+//   * `after_start_ticks` (2 s of the constant 100 MHz clock) from the moment the armed launch's first workgroup published
+//     `seq` in *started - NOT from when this waiter began: an armed rollout may sit behind seconds of queued compute-stream work
+//     (a PPO update, another job on the GPU), and a clock that started here gave up on launches that had not begun yet
+//     (ADVICE r03);
+//   * `total_ticks` (10 min) overall, against a launch that never runs at all (device fault after a successful enqueue).
+// On giving up the waiter POISONS this rank's payload - return = NaN, length = -1 for every env - writes `seq` into
+// *timeout_seq (pinned host memory, one word per buffer pair: rmav_allgather_stats_wait / _result report RMAV_ERR_TIMEOUT for
+// THAT post only) and lets the stream go on: the collective is still issued, so the peers neither hang nor mistake the
+// half-written snapshot for statistics.
+__global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, uint32_t count, uint32_t seq, const uint32_t *started,
+                                                       unsigned long long after_start_ticks, unsigned long long total_ticks,
+                                                       uint32_t *timeout_seq, int32_t *send, int64_t cmax) {
     const unsigned long long t0 = wall_clock64();
+    unsigned long long t_start = 0;   // per thread: when THIS thread first saw the launch begun (the give-up decision is made uniform below)
     for (;;) {
         int ok = 1;
         for (uint32_t i = threadIdx.x; i < count; i += 256u)
             ok &= (int32_t)(__hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0;
         if (__syncthreads_and(ok)) break;
-        if (__syncthreads_or(wall_clock64() - t0 > max_ticks)) {
-            if (threadIdx.x == 0) __hip_atomic_store(timeout_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long now = wall_clock64();
+        const int begun = __syncthreads_or((int32_t)(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0);
+        // (signed differences: the threads read the clock a few ticks apart, and an unsigned `now - t_start` of a thread that read
+        // it just BEFORE the one whose reading became t_start would wrap around to "expired")
+        int expired = (long long)(now - t0) > (long long)total_ticks;
+        if (begun) {
+            if (t_start == 0) t_start = now | 1ull;
+            expired |= (long long)(now - t_start) > (long long)after_start_ticks;
+        }
+        if (__syncthreads_or(expired)) {
+            for (int64_t i = threadIdx.x; i < cmax; i += 256) {
+                send[i] = 0x7fc00000;      // NaN
+                send[cmax + i] = -1;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(timeout_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             break;
         }
         __builtin_amdgcn_s_sleep(32);

@@ -82,7 +82,8 @@ struct rmav_env_s {
 };
 
 constexpr int kExchangeDepth = 8;   // buffer pairs of the overlapped statistics exchange
-constexpr unsigned long long kArrivalWaitTicks = 200000000ull;   // 2 s of the 100 MHz wall clock: bound of k_wait_arrivals
+// bounds of k_wait_arrivals, in ticks of the 100 MHz wall clock: 2 s once the armed launch has begun, 10 min overall
+constexpr unsigned long long kArrivalWaitTicks = 200000000ull, kArrivalTotalTicks = 60000000000ull;
 struct rmav_comm_s {
     uint32_t magic;
     int rank, world, device;
@@ -98,8 +99,11 @@ struct rmav_comm_s {
     int64_t cmax;      // capacity of the buffers (per-rank slots of 2 * cmax int32)
     int posts;         // number of posts so far (buffer pair of post i is i % depth)
     struct rmav_env_s *armed_by;   // the handle whose armed exchange points at this communicator (cleared by _post)
-    uint32_t *timeout_flag;        // pinned host word (device-mapped): k_wait_arrivals sets it when it gives up
-    uint32_t *timeout_flag_dev;
+    uint32_t *started;             // device word: the armed launch's first workgroup publishes its post number here
+    // pinned host words (device-mapped), one per buffer pair: k_wait_arrivals writes the post number it gave up on
+    uint32_t *timeout_seq, *timeout_seq_dev;
+    uint32_t slot_seq[kExchangeDepth];   // post number that last used each buffer pair
+    bool armed_slot[kExchangeDepth];     // ... and whether that post went through the waiter (an armed launch)
 };
 
 
@@ -123,9 +127,19 @@ inline void take_armed_exchange(rmav_handle h, rmav::RolloutArgs &a, int envs_pe
         a.xcmax = h->xchg.cmax;
         a.xarrive = c->arrive;
         a.xseq = h->xchg.seq;
+        a.xstarted = c->started;
         h->xchg.expected = (uint32_t)((h->n + envs_per_word - 1) / envs_per_word);
         h->xchg.fired = true;
     }
+}
+
+// Right after the hipLaunchKernelGGL of a rollout that may have taken the armed exchange: a launch that failed will never publish
+// its arrival words, so the exchange goes back to "armed, not fired" and rmav_allgather_stats_post packs as usual.
+inline int check_rollout_launch(rmav_handle h, const rmav::RolloutArgs &a) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return RMAV_OK;
+    if (a.xsend) h->xchg.fired = false;
+    return rmav_fail(RMAV_ERR_HIP, "rollout kernel launch failed: %s", hipGetErrorString(e));
 }
 
 // rmav_policy_abi.hip: launches rmav_rollout_policy's kernel for kmode = RMAV_ACT_POLICY | RMAV_ACT_POLICY_BF16 | ACT_POLICY_F32M |

@@ -156,6 +156,9 @@ struct RolloutArgs {
     int64_t xcmax;
     uint32_t *xarrive;
     uint32_t xseq;
+    // ... and the launch's first workgroup publishes xseq here as soon as it runs: the bound of the communicator stream's wait
+    // counts from THIS moment, not from when the waiter started (an armed launch may sit behind seconds of queued work)
+    uint32_t *xstarted;
     // k_step of a batch that fits ONE wavefront, outputs in the handle's pinned host block: the wavefront ends by publishing
     // done_seq in this pinned word (system-scope release), and the host spins on it instead of going through
     // hipStreamSynchronize (the kernel's end-of-kernel release + the completion signal + the runtime's wait: ~4 us of a
@@ -301,6 +304,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     if constexpr (is_split(MODE)) {
         if (a.n_steps <= 0) return;
     }
+
+    if (a.xsend && blockIdx.x == 0 && threadIdx.x == 0)   // (before the split modes' memory wavefronts return)
+        __hip_atomic_store(a.xstarted, a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;

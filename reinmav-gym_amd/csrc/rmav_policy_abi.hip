@@ -28,8 +28,7 @@ template <int K, int MODE> int launch_policy_1w(rmav_handle h, const RolloutArgs
     const int64_t per_wg = MODE == ACT_POLICY_F32M ? block_size(h) / 2 : block_size(h);
     hipLaunchKernelGGL((k_rollout<K, MODE, ST_DEFAULT>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(block_size(h)), lds, h->stream,
                        a, p, pc);
-    HIP_TRY(hipGetLastError());
-    return RMAV_OK;
+    return check_rollout_launch(h, a);
 }
 
 // The matrix-core actors as (actor, critic) wavefront pairs (rmav_policy_pair.hpp).  Pairs per workgroup: the pairs of a
@@ -46,8 +45,7 @@ template <int K, int FMT> int launch_rollout_pair(rmav_handle h, const RolloutAr
     const int64_t per_wg = 64 * g;
     hipLaunchKernelGGL((k_rollout_pair<K, FMT>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g), pair_lds_bytes<K>(g),
                        h->stream, a, p, pc);
-    HIP_TRY(hipGetLastError());
-    return RMAV_OK;
+    return check_rollout_launch(h, a);
 }
 
 template <int K> int launch_policy_k(rmav_handle h, int kmode, const RolloutArgs &a) {

@@ -236,6 +236,8 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     float *tile = lds_w + L::TOTAL + pair * PT::WORDS;   // this pair's hand-over tiles
     float *ztile = tile + lane, *otile = tile + PT::Z_WORDS + lane;
 
+    if (a.xsend && blockIdx.x == 0 && threadIdx.x == 0)   // armed statistics exchange: this launch has begun (see k_rollout)
+        __hip_atomic_store(a.xstarted, a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     {   // stage the weights of both nets (every thread helps), then derive the bias tables the activations need
         const float4 *src = reinterpret_cast<const float4 *>(a.policy_w);
         float4 *dst = reinterpret_cast<float4 *>(lds_w);

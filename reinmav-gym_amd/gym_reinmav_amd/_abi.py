@@ -101,9 +101,11 @@ PROTOTYPES = {
     "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp, C.c_int]),
     "rmav_gae": (C.c_int, [C.c_void_p, C.c_int32, _fp, _u8p, _fp, C.c_float, C.c_float, C.c_float, _fp, _fp, _vp]),
     "rmav_normalize": (C.c_int, [C.c_void_p, _fp, C.c_int64, C.c_float, C.c_float]),
+    "rmav_comm_use_library": (C.c_int, [C.c_char_p]),
     "rmav_comm_unique_id": (C.c_int, [C.c_void_p]),
     "rmav_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rmav_comm_destroy": (C.c_int, [C.c_void_p]),
+    "rmav_comm_warmup": (C.c_int, [C.c_void_p, C.c_double]),
     "rmav_allgather_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
     "rmav_allgather_stats_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rmav_allgather_stats_arm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

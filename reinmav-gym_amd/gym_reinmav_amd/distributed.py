@@ -148,10 +148,11 @@ class NativeStatsExchange:
     15 us of host time per post against ~100 us for ``all_gather_into_tensor`` behind Python, which matters when one
     exchange follows every ~100 us rollout launch.
 
-    ``connect_timeout_s``: bound the set-up.  ``rmav_comm_create`` (RCCL's rendezvous) runs on a helper thread that
-    touches nothing but the communicator; then ONE complete exchange is posted and awaited on the HOST with a deadline
-    (``rmav_allgather_stats_wait`` polls the gather's completion event), and only after it has completed is anything
-    enqueued on the env's stream.  On ``TimeoutError`` the env and its stream are therefore exactly as before - a caller
+    ``connect_timeout_s``: bound the set-up.  ``rmav_comm_create`` (RCCL's rendezvous) AND ``rmav_comm_warmup`` (a tiny
+    all-gather on the communicator's own stream: RCCL connects its transports inside the FIRST collective's enqueue, a
+    host-side exchange that blocks when a peer has died after the rendezvous) run on a helper thread that touches
+    nothing but the communicator and is joined with the deadline; then ONE complete exchange is posted and awaited on the
+    HOST with the rest of it (``rmav_allgather_stats_wait`` polls the gather's completion event).  On ``TimeoutError`` the env and its stream are therefore exactly as before - a caller
     can fall back to ``EpisodeStatsExchange`` on the same env - and the communicator is abandoned (never destroyed: a
     thread or a collective may still be inside RCCL)."""
 
@@ -201,6 +202,7 @@ class NativeStatsExchange:
             try:
                 with torch.cuda.device(dev):
                     create()
+                    A.check(L.rmav_comm_warmup(self._comm, -1.0))   # the first collective: transports connect here
             except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
                 box.append(e)
 
@@ -209,7 +211,7 @@ class NativeStatsExchange:
         th.join(connect_timeout_s)
         if th.is_alive():
             self._abandoned = True
-            raise TimeoutError(f"rmav_comm_create (RCCL rendezvous) did not complete in {connect_timeout_s} s")
+            raise TimeoutError(f"rmav_comm_create + warm-up collective (RCCL rendezvous and transport set-up) did not complete in {connect_timeout_s} s")
         if box:
             raise box[0]
         # one whole exchange before anybody relies on it: post (a pack + signal on the env's stream, the gather on the

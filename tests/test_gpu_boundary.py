@@ -211,7 +211,7 @@ for kind, n in (('quad3d', 4099), ('quad3d', 200000), ('quad2d_sl', 777), ('quad
                 lambda: env.rollout(16, mode='buffer', actions=acts, want=(), device_out=True),
                 lambda: env.rollout(4, mode='random', want=(), device_out=True)]       # n_steps < 8: the one-wavefront kernel
     if n <= 8192:
-        for kw in (dict(f32_mfma=False), dict(bf16_mfma=True), dict(f32_mfma=True)):
+        for kw in (dict(f32_mfma=False), dict(bf16_mfma=True), dict(f32_mfma=True), dict(f16_mfma=True)):
             col = FusedPolicyCollector(env, pol, 8, **kw)
             launches.append(col.collect)
     for fn in launches:
@@ -272,7 +272,38 @@ for kind, n in (('quad3d', 4099), ('quad3d', 200000), ('quad2d_sl', 777), ('quad
     A.check(L.rmav_allgather_stats_post(env._h, comm, n))
     r, l = gathered(env, comm, n)
     assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length'])
+    # one armed exchange per communicator: a second handle cannot arm it (its bookkeeping names ONE handle)
+    env2 = g.BatchedQuadrotor(kind, n, seed=3)
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+    assert L.rmav_allgather_stats_arm(env2._h, comm, n) == A.ERR_INVALID
+    env.rollout(16, mode='random', want=(), device_out=True)
+    A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+    A.check(L.rmav_allgather_stats_arm(env2._h, comm, n))                            # free again after the post
+    env2.close()                                                                     # destroying the armed handle disarms the communicator
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
+    env.rollout(16, mode='random', want=(), device_out=True)
+    A.check(L.rmav_allgather_stats_post(env._h, comm, n))
+    assert L.rmav_allgather_stats_wait(comm, 30.0) == 0
     A.check(L.rmav_comm_destroy(comm)); env.close()
+# An armed rollout that sits behind 3 s of other work on its stream (a PPO update, another job) must not time out: the 2 s bound
+# of the communicator stream's wait counts from the moment the armed launch BEGINS (ADVICE r03: it used to count from the post).
+env = g.BatchedQuadrotor('quad3d', 4099, seed=2)
+A.check(L.rmav_comm_unique_id(uid)); comm = C.c_void_p(); A.check(L.rmav_comm_create(C.byref(comm), uid, 0, 1, 0))
+import time
+st = torch.cuda.Stream(); env.use_stream(st)
+with torch.cuda.stream(st):
+    t0 = time.time(); torch.cuda._sleep(20_000_000); st.synchronize(); per = (time.time() - t0) / 20_000_000
+    A.check(L.rmav_allgather_stats_arm(env._h, comm, 4099))
+    t0 = time.time()
+    torch.cuda._sleep(int(3.0 / per))                                                # ~3 s of queued work ahead of the armed launch
+    env.rollout(16, mode='random', want=(), device_out=True)
+    A.check(L.rmav_allgather_stats_post(env._h, comm, 4099))                         # the waiter starts NOW, the launch in ~3 s
+    assert L.rmav_allgather_stats_wait(comm, 30.0) == 0, 'spurious time-out of a late armed launch'
+    waited = time.time() - t0
+    eb = env.episode_buffers()
+    r, l = gathered(env, comm, 4099)
+    assert np.array_equal(r, eb['last_return']) and np.array_equal(l, eb['last_length']) and waited > 2.2, waited
+A.check(L.rmav_comm_destroy(comm)); env.close()
 print('armed exchange ok', checked)
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)

@@ -1,2 +1,3 @@
-bash tools/profile_actors.sh r04_actors2 2>&1 | tail -12
-python bench.py --steps 100 --warmup 20 --cpu-seconds 0 --secondary policy_rollout > gpurun_out/r04_actors2/bench_policy.json 2> gpurun_out/r04_actors2/bench_policy.err; tail -c 3000 gpurun_out/r04_actors2/bench_policy.json
+mkdir -p gpurun_out/r04e
+export RMAV_STUB_WAIT_S=5
+timeout 900 python -m pytest tests/test_gpu_stub_rccl.py tests/test_gpu_boundary.py tests/test_gpu_multiprocess.py -x -q -m gpu > gpurun_out/r04e/pytest.log 2>&1; echo "pytest rc=$?"; tail -30 gpurun_out/r04e/pytest.log
