@@ -47,14 +47,6 @@ class ReinmavEnv(_EnvBase):
         """(F, Mx, My, Mz) the built-in controller commands at the current (state, t)  (reinmav_env.py:306-337)."""
         return self._batch.control()[0].astype(np.float64)
 
-    def trj_gen(self, t):   # reinmav_env.py:128-136 (host-side copy for callers that plot / inspect the reference path)
-        t_max = 4.0
-        t = np.maximum(0, np.minimum(t, t_max)) / t_max
-        pos = 10.0 * t**3 - 15.0 * t**4 + 6.0 * t**5
-        vel = (30 / t_max) * t**2 - (60 / t_max) * t**3 + (30 / t_max) * t**4
-        acc = (60 / t_max**2) * t - (180 / t_max**2) * t**2 + (120 / t_max**2) * t**3
-        return [pos, pos, pos, vel, vel, vel, acc, acc, acc, pos, vel]
-
     def reset(self):
         return self.state   # reinmav_env.py:348-351: returns the current state, changes nothing
 

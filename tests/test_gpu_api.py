@@ -97,12 +97,15 @@ def test_gym_env_attributes(G):
     e2.close()
 
 
-@pytest.mark.parametrize("numpy_io", [False, True])
-def test_vec_env_contract(G, numpy_io):
+@pytest.mark.parametrize("numpy_io,lazy", [(False, False), (True, False), (False, True), (True, True)])
+def test_vec_env_contract(G, numpy_io, lazy):
+    """lazy: the infos of a big batch (> 4 096 envs by default; forced here) are a list-like that is materialised on first use -
+    the same `len(infos) == num_envs` / `infos[i]['episode']` contract a baselines Runner iterates."""
     import torch
 
     n, seed = 512, 9
-    venv = G.QuadrotorVecEnv("quadrotor3d-v0", n, seed=seed, numpy_io=numpy_io)
+    venv = G.QuadrotorVecEnv("quadrotor3d-v0", n, seed=seed, numpy_io=numpy_io, dict_infos=not lazy)
+    assert G.QuadrotorVecEnv.__init__.__defaults__ is not None and venv.dict_infos == (not lazy)
     assert venv.num_envs == n and venv.observation_space.shape == (10,) and venv.action_space.shape == (4,)
     obs = venv.reset()
     to_np = (lambda x: x) if numpy_io else (lambda x: x.cpu().numpy())
@@ -136,10 +139,24 @@ def test_vec_env_contract(G, numpy_io):
             ep_ret[done] = 0
             ep_len[done] = 0
         assert all("episode" not in infos[i] for i in np.nonzero(~done)[0][:16])
+        if k % 50 == 0:   # what ppo2's Runner does with them: `for info in infos: maybeepinfo = info.get('episode')`
+            assert sum(1 for info in infos if info.get("episode")) == int(done.sum())
+            assert isinstance(infos[-1], dict) and len(infos[:3]) == 3
         rc += done.astype(np.uint32)
         prev = obs
     assert saw_episode
+    if lazy:   # infos not read before the next step cannot report that step's statistics any more: an error, not stale numbers
+        a = rng.uniform(0, 10, (n, 4)).astype(np.float32)
+        old = venv.step(a if numpy_io else torch.from_numpy(a).cuda())[3]
+        venv.step(a if numpy_io else torch.from_numpy(a).cuda())
+        with pytest.raises(RuntimeError):
+            old[0]
     venv.close()
+    big = G.QuadrotorVecEnv("quadrotor3d-v0", 8192, seed=seed)       # the default beyond 4 096 envs
+    big.reset()
+    infos = big.step(torch.zeros((8192, 4), device="cuda"))[3]
+    assert len(infos) == 8192 and isinstance(infos[5], dict)
+    big.close()
 
 
 def test_error_behaviour(G):

@@ -105,6 +105,57 @@ def test_control_vs_reference_golden(G, kind, golden):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_reference_closed_loop_trajectories_replayed_on_the_gpu(G, kind, golden):
+    """The reference's own test loop (test/test_quadrotor3d.py:16-22 and siblings: control() -> step() -> reset() on done,
+    400 steps x 4 seeds, recorded by tests/golden/make_golden.py from the imported reference) replayed on the GPU for EVERY
+    kind: all 1 600 recorded pre-step states as one batch, control() against the recorded actions, step() of the recorded
+    actions against the recorded next states / rewards / dones - HIP output vs the reference's output, no oracle in between.
+    steps_beyond_done is set to what the reference's env object held at that point of its life (the terminal reward is 1.0 only
+    for an env object's first termination: quirk Q1).  Slung-load kinds: a step that starts with |tether| - L below 2e-6 - every
+    step after a taut one, the projection puts the load exactly at L - hangs on the last bit of a norm the fp32 state cannot
+    carry; there the HIP step must equal the oracle's taut or slack step from the same fp32 state."""
+    g = golden[kind]
+    for sfx in ([""] + (["_A"] if kind == "quad2d" else [])):
+        S, A_, S2, R, D = (g["traj_" + k + sfx] for k in ("s", "a", "s2", "r", "d"))
+        E, T = S.shape[:2]
+        n = E * T
+        D = D.astype(bool)
+        env = G.BatchedQuadrotor(kind, n, seed=1, auto_reset=False, track_episodes=False, reading_2d=("A" if sfx else None))
+        s32 = S.reshape(n, -1).astype(np.float32)
+        earlier = (np.cumsum(D, axis=1) - D).reshape(n)              # terminations of this env object before this step
+        env.set_state(s32)
+        env.set_sbd(np.where(earlier == 0, -1, earlier - 1).astype(np.int32))
+        a = env.control()
+        # the recorded state is rounded to fp32 on entry; the controllers amplify that by their gains (kp/tau ~ 50)
+        assert scaled_err(a, A_.reshape(n, -1)).max() <= 1e-5, (kind, sfx)
+        a32 = A_.reshape(n, -1).astype(np.float32)
+        obs, rew, done = env.step(a32)
+        done = np.asarray(done).astype(bool)
+        s2, r, d = S2.reshape(n, -1), R.reshape(n), D.reshape(n)
+        p = O.default_params(kind, "A" if sfx else "B")
+        slack = O.tether_slack(kind, s32.astype(np.float64), p)
+        edge = np.abs(slack) < 2e-6 if kind in ("quad2d_sl", "quad3d_sl") else np.zeros(n, bool)
+        ok = ~edge
+        err = scaled_err(obs, s2)
+        # (fp32 inputs vs the reference's fp64 ones: 2e-6 instead of the 1e-6 of identical inputs)
+        assert err[ok].max() <= 2e-6, (kind, sfx, float(err[ok].max()))
+        near = near_threshold(kind, s2, limits=(p.pos_limit, p.vel_limit))
+        assert np.array_equal((done | near)[ok], (d | near)[ok])
+        same = ok & (done == d)
+        assert scaled_err(rew[same], r[same]).max() <= 2e-6
+        assert int(d.sum()) >= 1 and int((earlier > 0).sum()) >= 1     # the fixtures do contain terminations and second lives
+        if edge.any():   # either branch of the oracle, from the very state and action the device saw
+            idx = np.nonzero(edge)[0]
+            best = np.full(len(idx), np.inf)
+            for ft in (0, 1):
+                o2 = np.stack([O.step(kind, s32[i].astype(np.float64), a32[i].astype(np.float64), None, params=p, force_taut=ft)[0] for i in idx])
+                best = np.minimum(best, scaled_err(obs[idx], o2).max(axis=1))
+            assert best.max() <= TOL, (kind, float(best.max()))
+            assert ok.sum() > n // 4                                    # and a good part of the loop is compared with the reference directly
+        env.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_reset_streams_bit_exact_and_shard_invariant(G, kind):
     n, seed = 3000, 77
     env = G.BatchedQuadrotor(kind, n, seed=seed)

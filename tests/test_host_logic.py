@@ -30,6 +30,71 @@ def test_registry_ids_match_reference():
         g.make("MujocoQuadForce-v0")  # out of scope, not silently mapped to something else
 
 
+def test_register_envs_with_a_stub_gym(monkeypatch):
+    """register_envs() against a stand-in `gym` (the image has neither gym nor gymnasium): the five ids of the reference's
+    gym_reinmav/__init__.py:3-26 are registered, each with an entry point that resolves to the class of that name."""
+    import importlib
+    import sys
+    import types
+
+    import gym_reinmav_amd as g
+    from gym_reinmav_amd import registration
+
+    calls = []
+    gym = types.ModuleType("gym")
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda id, entry_point, **kw: calls.append((id, entry_point))   # noqa: A002 - gym's own keyword
+    gym.envs, envs.registration = envs, reg
+    for name, mod in (("gym", gym), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    assert registration.register_envs() is True
+    assert dict(calls) == g.ENTRY_POINTS and len(calls) == 5
+    want = {"reinmav-v0": "ReinmavEnv", "quadrotor2d-v0": "Quadrotor2D", "quadrotor2d-slungload-v0": "Quadrotor2DSlungload",
+            "quadrotor3d-v0": "Quadrotor3D", "quadrotor3d-slungload-v0": "Quadrotor3DSlungload"}
+    for env_id, ep in calls:
+        mod, cls = ep.split(":")
+        assert cls == want[env_id]                                   # the reference's class names
+        assert mod.endswith("envs.native")                           # ... in the package path the reference uses (gym_reinmav.envs.native)
+        klass = getattr(importlib.import_module(mod), cls)
+        assert all(hasattr(klass, m) for m in ("step", "reset", "seed", "close", "render"))
+    # a registry that already holds an id (gym raises on duplicates) must not break the others
+    def picky(id, entry_point, **kw):   # noqa: A002
+        if id == "quadrotor3d-v0":
+            raise RuntimeError("Cannot re-register id")
+        calls.append((id, entry_point))
+    calls.clear()
+    reg.register = picky
+    assert registration.register_envs() is True and len(calls) == 4
+
+
+def test_lazy_infos_list_contract():
+    """LazyInfos without a GPU: len / index / negative index / slice / iteration / .get('episode'), one fetch of the statistics."""
+    from gym_reinmav_amd.vec_env import LazyInfos
+
+    fetched = []
+
+    class FakeBatch:
+        def episode_buffers(self):
+            fetched.append(1)
+            return {"last_return": np.arange(8, dtype=np.float32) * -1.5, "last_length": np.arange(8, dtype=np.int32) + 10}
+
+    class FakeVec:
+        env, _info_seq = FakeBatch(), 3
+
+    done = np.array([0, 1, 0, 0, 0, 0, 1, 0], bool)
+    infos = LazyInfos(8, done, FakeVec(), 3)
+    assert len(infos) == 8 and not fetched
+    assert infos[1] == {"episode": {"r": -1.5, "l": 11}} and infos[-2]["episode"]["l"] == 16 and infos[0] == {}
+    assert [bool(i.get("episode")) for i in infos] == list(done) and len(infos[2:5]) == 3 and len(fetched) == 1
+    assert sorted(infos.finished()) == [1, 6]
+    with pytest.raises(IndexError):
+        infos[8]
+    stale = LazyInfos(8, done, FakeVec(), 2)
+    with pytest.raises(RuntimeError):
+        stale[0]
+
+
 def test_box_space():
     from gym_reinmav_amd.spaces import Box
 
