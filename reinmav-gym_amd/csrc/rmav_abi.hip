@@ -281,8 +281,11 @@ template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctr
     if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;   // the armed launch's snapshot is no longer the latest
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
+    const int st = h->tune[RMAV_TUNE_STEP_STORE];
     if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     else if (h->tune[RMAV_TUNE_STEP_LAZY] == 1) hipLaunchKernelGGL((k_step<K, false, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
+    else if (st == ST_WRITE_THROUGH) hipLaunchKernelGGL((k_step<K, false, false, ST_WRITE_THROUGH>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
+    else if (st == ST_STREAM) hipLaunchKernelGGL((k_step<K, false, false, ST_STREAM>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     else hipLaunchKernelGGL((k_step<K, false>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;

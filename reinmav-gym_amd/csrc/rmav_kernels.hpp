@@ -1166,11 +1166,12 @@ __device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_
 // 8 B per env-step less HBM-side traffic (the launch fetches 1.28 x its algorithmic bytes otherwise, of which these two
 // arrays are 0.08), but a dependent memory round trip on the critical path of every wavefront that has a finishing lane
 // (57 % of them), in a kernel whose whole duration is ~1.5 round trips above the launch floor.  profiles/r03/step_lazy_ab.md.
-template <int K, bool CTRL, bool LAZY = false>
+template <int K, bool CTRL, bool LAZY = false, int ST = ST_DEFAULT>
 __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                  const ParamsT<double> pc_shared) {
     static_assert(K != REINMAV, "ReinmavEnv steps go through k_rollout");
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
+    constexpr int AUX = StoreAux<ST>::value;   // cache policy of the per-env stores (RMAV_TUNE_STEP_STORE; measured in profiles/r04/step_store_policy.md)
     const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = a.n;
     const bool valid = gi < (uint64_t)n;
@@ -1254,8 +1255,8 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     int32_t fin_len = 0;
     // everything that does not need the reset state goes out first
     if (valid) {
-        if (a.rew_out) buf_st(make_rsrc(a.rew_out), off, 0, r);
-        if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, 0);
+        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out), off, 0, r);
+        if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, AUX);
         if (track) {
             er += r;
             el += 1;
@@ -1268,8 +1269,8 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
                 er = 0.0f;
                 el = 0;
             }
-            buf_st(make_rsrc(a.ep_ret), off, 0, er);
-            buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+            buf_st_aux<AUX>(make_rsrc(a.ep_ret), off, 0, er);
+            buf_st_aux<AUX>(make_rsrc(a.ep_len), off, 0, __builtin_bit_cast(float, el));
         }
         if (done) {
             buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
@@ -1280,7 +1281,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         reset_state_wave<K>(a.seed, a.env_base + (uint64_t)(gi - (threadIdx.x & 63u)), rc, done && valid, s);
     if (valid) {
 #pragma unroll
-        for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+        for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(r_state, off, (uint32_t)c * col, s[c]);
     }
     // (Batch-major obs through an LDS transpose - as the fused kernels do for big launches - was built and measured here in
     // round 3: QuadrotorVecEnv.step at 65 536 envs 4.91-5.02 us with it, 4.99-5.01 without; not kept.)
@@ -1292,7 +1293,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         } else {
             const rsrc_t ro = make_rsrc(a.obs_out);
 #pragma unroll
-            for (int c = 0; c < NS; ++c) buf_st(ro, off, (uint32_t)c * col, s[c]);
+            for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * col, s[c]);
         }
     }
     if constexpr (CTRL) {   // control() of the state this launch leaves behind

@@ -143,7 +143,8 @@ def test_reference_closed_loop_trajectories_replayed_on_the_gpu(G, kind, golden)
         assert np.array_equal((done | near)[ok], (d | near)[ok])
         same = ok & (done == d)
         assert scaled_err(rew[same], r[same]).max() <= 2e-6
-        assert int(d.sum()) >= 1 and int((earlier > 0).sum()) >= 1     # the fixtures do contain terminations and second lives
+        if kind == "quad2d":   # (its controller's thrust is scaled x10 by step(): the loop diverges and restarts - quirk Q8)
+            assert int(d.sum()) >= 1 and int((earlier > 0).sum()) >= 1     # the fixture does contain terminations and second lives
         if edge.any():   # either branch of the oracle, from the very state and action the device saw
             idx = np.nonzero(edge)[0]
             best = np.full(len(idx), np.inf)
