@@ -317,21 +317,26 @@ def test_fused_rollouts_repeat_bit_for_bit_at_four_wavefronts_per_simd(G, kind, 
 
 @pytest.mark.parametrize("kind", KINDS)
 def test_single_step_variants_give_the_same_bits(G, kind):
-    """rmav_step through k_step (default), k_step with lane-predicated counter loads (RMAV_TUNE_STEP_LAZY) and the rollout
-    kernel at n_steps = 1 (RMAV_TUNE_STEP_KERNEL = 0): same outputs, state, counters and episode statistics, bit for bit,
-    over 60 steps with ~1 % of the lanes terminating per step (ragged batch: the last wavefront has clones)."""
+    """rmav_step through k_step (batch- and feature-major), its write-through / non-temporal store variants, k_step with
+    lane-predicated counter loads
+    (RMAV_TUNE_STEP_LAZY) and the rollout kernel at n_steps = 1 (RMAV_TUNE_STEP_KERNEL = 0): same outputs, state, counters and
+    episode statistics, bit for bit, over 60 steps with ~1 % of the lanes terminating per step (ragged batch: the last
+    wavefront has clones)."""
     import hashlib
 
     n = 4099
     lo, hi = BOX[kind]
     acts = np.random.RandomState(3).uniform(lo, hi, (60, n, NA[kind])).astype(np.float32)
     digests = {}
-    for name, tune in (("k_step", {}), ("lazy", {"step_lazy": 1}), ("rollout kernel", {"step_kernel": 0})):
+    for name, tune, layout in (("k_step", {}, "aos"), ("feature-major", {}, "soa"), ("write-through", {"step_store": 1}, "aos"),
+                               ("non-temporal", {"step_store": 2}, "soa"), ("lazy", {"step_lazy": 1}, "aos"),
+                               ("rollout kernel", {"step_kernel": 0}, "aos")):
         env = G.BatchedQuadrotor(kind, n, seed=8, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
         h = hashlib.sha256()
         for k in range(60):
-            for x in env.step(acts[k]):
+            out = env.step(acts[k] if layout == "aos" else np.ascontiguousarray(acts[k].T), layout=layout)
+            for x in (out[0] if layout == "aos" else out[0].T, out[1], out[2]):
                 h.update(np.ascontiguousarray(x).tobytes())
         for x in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
             h.update(np.ascontiguousarray(x).tobytes())
