@@ -183,9 +183,12 @@ def roofline_obj(bytes_launch: float, launch_ms: float, traffic, traffic_src, de
     return r
 
 
-def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, label: str, tune=None):
+def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, label: str, tune=None, per_env_params=False,
+                cpu_seconds: float = 0.0):
     """One more single-GPU BASELINE config as its own short measurement: fused random-action rollouts of `kind` over `n` envs
-    into a cold ring of trajectory buffer sets, timed with HIP events on the launch stream (same method as the headline)."""
+    into a cold ring of trajectory buffer sets, timed with HIP events on the launch stream (same method as the headline).
+    per_env_params: every env gets its own mass / load mass / tether length (rmav_set_env_param: SURVEY 8f-4, the constants
+    the reference hard-codes in quadrotor3d_slungload.py:45-59), +-10 % around the defaults."""
     A = g._abi
     K_ = A.KIND_BY_NAME[kind]
     nS, nA = A.STATE_DIM[K_], A.ACTION_DIM[K_]
@@ -196,6 +199,11 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
         env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
         if tune:
             env.set_tuning(**tune)
+        if per_env_params:
+            gen = torch.Generator(device="cpu").manual_seed(1)
+            pr = env.params
+            for name, base in (("mass", pr.mass), ("load_mass", pr.load_mass), ("tether_length", pr.tether_length)):
+                env.set_env_param(name, (base * (0.9 + 0.2 * torch.rand(n, generator=gen))).to(torch.float32).numpy())
         ring = [{"actions": torch.zeros((chunk, nA, n), dtype=torch.float32, device=dev),
                  "obs": torch.zeros((chunk, nS, n), dtype=torch.float32, device=dev),
                  "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
@@ -219,14 +227,19 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
         env.close()
     del ring
     torch.cuda.empty_cache()
-    b = fused_bytes_per_launch(n, chunk, nS, nA)
-    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa")
-    return {"workload": f"{label}: {ENV_ID[kind]}, {n} envs, random actions, auto-reset, episode tracking; {chunk}-step fused launches "
-                        f"into a ring of {R} trajectory buffer sets ({R * per_set / 1e9:.2f} GB: cold stores)",
-            "launches": K, "warmup": W, "value": n * chunk * K / wall, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * wall / K,
-            "finished_episodes": fin,
-            "roofline": roofline_obj(b, ms, tr, src, f"{n} envs x ({chunk} env-steps x {4 * (nS + nA + 1) + 1} B trajectory out + "
-                                                     f"{8 * nS + 24} B state / episode bookkeeping per launch)")}
+    b = fused_bytes_per_launch(n, chunk, nS, nA) + (12 * n if per_env_params else 0)
+    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa" + (":pe" if per_env_params else ""))
+    out = {"workload": f"{label}: {ENV_ID[kind]}, {n} envs, random actions, auto-reset, episode tracking; {chunk}-step fused launches "
+                       f"into a ring of {R} trajectory buffer sets ({R * per_set / 1e9:.2f} GB: cold stores)" +
+                       ("; per-env mass, load mass and tether length (3 x 4 B per env and launch read, constants re-derived per lane)" if per_env_params else ""),
+           "launches": K, "warmup": W, "value": n * chunk * K / wall, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * wall / K,
+           "finished_episodes": fin,
+           "roofline": roofline_obj(b, ms, tr, src, f"{n} envs x ({chunk} env-steps x {4 * (nS + nA + 1) + 1} B trajectory out + "
+                                                    f"{8 * nS + 24 + (12 if per_env_params else 0)} B state / episode bookkeeping per launch)")}
+    if cpu_seconds > 0:   # the same workload on the host cores (C oracle, one thread): the side-by-side of BASELINE.md section 4
+        p = g._abi.default_params(K_)
+        out["cpu_baseline"] = cpu_baseline(kind, min(n, 65536), chunk, float(p.act_lo), float(p.act_hi), cpu_seconds, threads=1)
+    return out
 
 
 def main():
@@ -257,7 +270,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
     ap.add_argument("--tune", default="", help="comma list of key=value overrides of the launch heuristics (rmav_set_tuning), "
                                                "e.g. split=0,store_policy=2")
-    ap.add_argument("--secondary", default="in_place,step,c3_shard,c4,gym1,vecenv,policy",
+    ap.add_argument("--secondary", default="in_place,step,c3_shard,c4,c4_pe,reinmav,gym1,vecenv,policy,sustained",
                     help="comma list of the other measurements to add under other_modes (single process only)")
     args = ap.parse_args()
 
@@ -480,7 +493,17 @@ def main():
                 if "c3_shard" in sec and n != 131072:
                     other["c3_shard"] = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 600, 150, "BASELINE configs[2]'s per-GPU shard")
                 if "c4" in sec:
-                    other["c4"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80, "BASELINE configs[3] (C4)")
+                    other["c4"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80, "BASELINE configs[3] (C4)",
+                                              cpu_seconds=min(3.0, args.cpu_seconds))
+                if "c4_pe" in sec:
+                    other["c4_per_env_params"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80,
+                                                             "BASELINE configs[3] (C4) with per-env constants", per_env_params=True)
+                    if "c4" in other:
+                        a_, b_ = other["c4"]["roofline"]["launch_ms_hip_events"], other["c4_per_env_params"]["roofline"]["launch_ms_hip_events"]
+                        other["c4_per_env_params"]["vs_shared_constants"] = {"us_per_launch": 1e3 * b_, "us_per_launch_shared": 1e3 * a_,
+                                                                             "extra_us": 1e3 * (b_ - a_), "extra_bytes_per_launch": 12 * 262144}
+                if "reinmav" in sec:
+                    other["reinmav"] = bench_reinmav(g, torch, dev, cpu_seconds=min(3.0, args.cpu_seconds))
             except Exception as e:  # pragma: no cover
                 other["legs_error"] = repr(e)
         # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
@@ -489,6 +512,17 @@ def main():
             wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
                                                                prewarm_ms=args.prewarm_ms)
         device_state = sampler.summary()
+        if single and "sustained" in sec and args.mode == "rollout":
+            # >= 2.5 s of the headline launches back to back (outside the K timed ones): a stretch long enough for clocks and the
+            # package power limit to settle, and for an outside busy sampler to see the GPU at work at all - the K = 20 launches
+            # of the driver's default command are 0.9 ms of a ~20 s process
+            k_s = max(args.steps, int(2.5 / max(1e-6, kernel_ms * 1e-3)))
+            with DeviceSampler(dev.index or 0) as sampler2:
+                w_s, kms_s, pl_s, _, _ = measure(args.mode, args.chunk, k_s, 0, args.in_place, prewarm_ms=0.0)
+            other["sustained"] = {"workload": "the headline launches, back to back for >= 2.5 s", "seconds": w_s, "launches": k_s,
+                                  "value": n_total * pl_s * k_s / w_s, "unit": "env-steps/s", "ms_per_launch_hip_events": kms_s,
+                                  "roofline_frac": fused_bytes_per_launch(n, pl_s, nS, nA) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "device_state": sampler2.summary()}
         totals = env.episode_totals()
         exchange_check = None
         if use_dist and exchange is not None and args.mode == "rollout":
@@ -531,6 +565,8 @@ def main():
                 other["vecenv"] = bench_vecenv(dev, n)
             if "policy" in sec and kind != "reinmav":
                 other["policy_rollout"] = bench_policy(dev, kind, n)
+                if args.cpu_seconds > 0:
+                    other["policy_rollout"]["cpu_baseline"] = cpu_policy_baseline(kind, min(3.0, args.cpu_seconds))
         except Exception as e:  # pragma: no cover - never lose the headline line to a secondary leg
             other["error"] = repr(e)
 
@@ -615,6 +651,9 @@ def main():
         }
         if other:
             line["other_modes"] = other
+        calib = os.path.join(ROOT, "profiles", "cpu_calibration.json")
+        if os.path.exists(calib):   # build-CPU / reference ratio per kind, measured in the authoring container (oracle/calibrate.py)
+            line["calibration"] = json.load(open(calib))
         if world == 1 and not use_dist and args.cpu_seconds > 0 and kind != "reinmav":
             line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
             ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -654,6 +693,99 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_reinmav(g, torch, dev, n: int = 65536, chunk: int = 4, K: int = 30, W: int = 8, cpu_seconds: float = 0.0):
+    """ReinmavEnv (reinmav_env.py:90-126,188-264) batched - 13-state rigid body, 50-or-51 Euler sub-steps of 1/5000 s
+    per env-step with the built-in PD controller evaluated every sub-step, all in fp64.  The one compute-bound kind: its roofline
+    is the fp64 vector ALU (78.6 TFLOP/s dense, MI355X_MICROARCH.md), flops counted from the kernel's ISA
+    (k_rollout<REINMAV, ACT_CONTROLLER>: ~850 fp64 flops per sub-step with fma = 2, x 50.47 sub-steps per step on average)."""
+    stream = torch.cuda.Stream(device=dev)
+    flops_per_step = 850.0 * 50.47
+    with torch.cuda.stream(stream):
+        env = g.BatchedQuadrotor("reinmav", n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        s0 = env.get_state(layout="aos")
+        gen = torch.Generator(device="cpu").manual_seed(2)
+        env.set_state(s0 + 0.05 * torch.randn(s0.shape, generator=gen).numpy().astype(s0.dtype))   # (they all start from one state)
+        out = {"obs": torch.zeros((chunk, env.nS, n), dtype=torch.float32, device=dev), "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
+               "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev)}
+        for phase, count in (("warm", W), ("timed", K)):
+            if phase == "timed":
+                stream.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(stream)
+            for _ in range(count):
+                env.rollout(chunk, mode="controller", layout="soa", fused=True, want=("obs", "rew", "done"), device_out=True, out=out)
+        e1.record(stream)
+        stream.synchronize()
+        wall = time.perf_counter() - t0
+        ms = e0.elapsed_time(e1) / K
+        env.close()
+    ach = flops_per_step * n * chunk / (ms * 1e-3) / 1e12
+    res = {"workload": f"reinmav-v0 batched: {n} envs, {chunk} env-steps per launch = ~{chunk * 50.47:.0f} Euler sub-steps with the built-in controller "
+                       "in every sub-step (the reference's ReinmavEnv.step), obs / reward / done written per env-step",
+           "launches": K, "value": n * chunk * K / wall, "unit": "env-steps/s", "ms_per_launch_hip_events": ms,
+           "sub_steps_per_s": 50.47 * n * chunk * K / wall,
+           "roofline": {"bound": "valu_fp64", "achieved": ach, "peak": 78.6, "unit": "TFLOP/s", "frac": ach / 78.6,
+                        "flops_per_env_step": flops_per_step,
+                        "flops_definition": "~850 fp64 flops per sub-step (v_fma_f64 = 2, v_mul / v_add_f64 = 1, counted in the ISA of the sub-step "
+                                            "loop incl. the controller's sin / cos / atan2 / asin expansions) x 50.47 sub-steps per step",
+                        "note": "~1 070 instructions per sub-step, 780 of them fp64 at half rate, one dependent chain per env: issue- and "
+                                "latency-bound well below the flop peak at 1 - 2 wavefronts per SIMD"}}
+    if cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import numpy as np
+
+        import oracle as O
+
+        S = np.tile(np.asarray(s0[:1], np.float64), (256, 1)) + 0.05 * np.random.RandomState(0).randn(256, 13)
+        Tt = np.zeros(256)
+        done_steps, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < cpu_seconds:
+            S, Tt, _ = O.reinmav_batch_step(S, Tt)
+            done_steps += 256
+        el = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": done_steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                               "sample": f"reinmav C oracle (fp64, scalar code, 1 thread), 256 envs x {done_steps // 256} env-steps with the built-in "
+                                         f"controller, {el:.1f} s on the GPU box's host CPU (the reference's own step: BASELINE.md section 2)"}
+    return res
+
+
+def cpu_policy_baseline(kind: str, budget_s: float, n: int = 4096):
+    """C5's per-env work on ONE host core: the fp32 2x64 tanh MLP policy + value net as NumPy matrix products (feature-major, like
+    the learner's torch form) + the C oracle's env step, for a batch of n envs - what the rollout of gym_reinmav/run.py:63-68 costs
+    per env-step without a GPU, less baselines' own Python."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+
+    import oracle as O
+
+    _omp_set_threads(1)
+    nS, nA = O.STATE_DIM[kind], O.ACTION_DIM[kind]
+    rng = np.random.RandomState(0)
+    W = [[(rng.randn(o, i) * 0.1).astype(np.float32) for i, o in ((nS, 64), (64, 64), (64, k))] for k in (nA, 1)]
+    s = rng.uniform(-1, 1, (n, nS)).astype(np.float32)
+    sbd = np.full(n, -1, np.int32)
+    steps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        x = s.T
+        outs = []
+        for net in W:
+            h = x
+            for li, w in enumerate(net):
+                h = w @ h
+                if li < 2:
+                    h = np.tanh(h)
+            outs.append(h)
+        act = (outs[0] + rng.standard_normal(outs[0].shape).astype(np.float32)).T
+        s2, _, d, sbd = O.batch_step(kind, s.astype(np.float64), act.astype(np.float64), sbd)
+        s = np.where(d[:, None], rng.uniform(-1, 1, (n, nS)), s2).astype(np.float32)
+        steps += n
+    el = time.perf_counter() - t0
+    return {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{kind}: NumPy fp32 2x64 tanh MLP policy + value net (single-threaded BLAS not enforced: {os.cpu_count()} logical cores present) + "
+                      f"C oracle step, {n} envs x {steps // n} env-steps, {el:.1f} s"}
 
 
 # ---- the boundaries the reference's callers use (reported under other_modes) ---------------------------------------
