@@ -762,6 +762,12 @@ def cpu_policy_baseline(kind: str, budget_s: float, n: int = 4096):
     import oracle as O
 
     _omp_set_threads(1)
+    try:   # one BLAS thread: the number is per core
+        from threadpoolctl import threadpool_limits
+
+        limit, blas = threadpool_limits(limits=1), "one BLAS thread"
+    except Exception:  # pragma: no cover
+        limit, blas = None, f"BLAS threads not limited, {os.cpu_count()} logical cores present"
     nS, nA = O.STATE_DIM[kind], O.ACTION_DIM[kind]
     rng = np.random.RandomState(0)
     W = [[(rng.randn(o, i) * 0.1).astype(np.float32) for i, o in ((nS, 64), (64, 64), (64, k))] for k in (nA, 1)]
@@ -783,9 +789,10 @@ def cpu_policy_baseline(kind: str, budget_s: float, n: int = 4096):
         s = np.where(d[:, None], rng.uniform(-1, 1, (n, nS)), s2).astype(np.float32)
         steps += n
     el = time.perf_counter() - t0
+    if limit is not None:
+        limit.restore_original_limits()
     return {"value": steps / el, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{kind}: NumPy fp32 2x64 tanh MLP policy + value net (single-threaded BLAS not enforced: {os.cpu_count()} logical cores present) + "
-                      f"C oracle step, {n} envs x {steps // n} env-steps, {el:.1f} s"}
+            "sample": f"{kind}: NumPy fp32 2x64 tanh MLP policy + value net ({blas}) + C oracle step, {n} envs x {steps // n} env-steps, {el:.1f} s"}
 
 
 # ---- the boundaries the reference's callers use (reported under other_modes) ---------------------------------------

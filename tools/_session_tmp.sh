@@ -1,4 +1,11 @@
-mkdir -p gpurun_out/r04g
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_api.py -x -q -m gpu > gpurun_out/r04g/pytest.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/r04g/pytest.log
-python tools/vecenv_ab.py step_fast=0 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04g/vecenv_ab.txt
-for T in "" "--tune step_fast=0" "" "--tune step_fast=0"; do python bench.py --mode step --steps 4000 --warmup 500 --cpu-seconds 0 --no-secondary $T 2>/dev/null | grep '^{' | python -c "import sys,json; j=json.loads(sys.stdin.read()); print('step mode $T', round(j['roofline']['launch_ms_hip_events']*1e3,3), 'us')"; done | tee gpurun_out/r04g/step_fast.txt
+mkdir -p gpurun_out/r04h
+python bench.py --steps 20 --warmup 5 > gpurun_out/r04h/bench_n1_k20.json 2> gpurun_out/r04h/bench_n1_k20.err; echo "bench rc=$?"; python - <<'PY'
+import json
+j = json.loads([l for l in open("gpurun_out/r04h/bench_n1_k20.json") if l.startswith("{")][-1])
+print("value", j["value"] / 1e9, "frac", j["roofline"]["frac"])
+for k, v in j.get("other_modes", {}).items():
+    print(k, json.dumps(v)[:600])
+print("cpu", json.dumps(j.get("cpu_baseline"))[:200], json.dumps(j.get("calibration"))[:200])
+PY
+tail -3 gpurun_out/r04h/bench_n1_k20.err
+bash tools/throttle_probe.sh r04h 2>&1 | tail -60

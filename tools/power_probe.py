@@ -65,6 +65,10 @@ while time.perf_counter() - t_start < secs:
     e1.record(); torch.cuda.synchronize()
     rows.append((time.perf_counter() - t_start, e0.elapsed_time(e1) * 10))
 stop = True; th.join()
+if os.environ.get("SERIES"):   # time series: launch time per 100-launch slice, and the sampled power / clocks
+    with open(os.environ["SERIES"], "w") as f:
+        f.write("# t_s us_per_launch\n" + "".join(f"L {t:.3f} {u:.2f}\n" for t, u in rows))
+        f.write("# t_s power_w sclk_mhz fclk_mhz mclk_mhz\n" + "".join(f"S {t - t_start:.3f} {p:.0f} {c:.0f} {fc:.0f} {m:.0f}\n" for t, p, c, fc, m in samples))
 steady = [u for t, u in rows if t > secs / 2]
 burst = min(u for t, u in rows)
 sp = [(p, c, f, m) for t, p, c, f, m in samples if t - t_start > secs / 2]
