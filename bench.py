@@ -882,13 +882,15 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
     mix_path = os.path.join(ROOT, "profiles", "actor_instr_mix.json")
     mix = json.load(open(mix_path)) if os.path.exists(mix_path) else {}
     # bf16_1w: round 3's kernel (one wavefront per 64 envs); bf16_mfma / f16_mfma: (actor, critic) wavefront pairs (rmav_policy_pair.hpp)
-    for actor in ("fp32_valu", "fp32_mfma", "bf16_1w", "bf16_mfma", "f16_mfma"):
+    # f16_shared: a DIFFERENT architecture - one 2x64 trunk with a mean head and a value head (baselines' value_network = 'shared': what
+    # ppo2 builds for gym_reinmav's native env type) - half the activations of the two-net policy the other rows evaluate
+    for actor in ("fp32_valu", "fp32_mfma", "bf16_1w", "bf16_mfma", "f16_mfma", "f16_shared"):
         torch.manual_seed(0)
         env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
         if actor == "bf16_1w":
             env.set_tuning(policy_pair=0)
-        pol = MlpPolicy(env.nS, env.nA).to(dev)
-        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f32_mfma=(actor == "fp32_mfma"), f16_mfma=(actor == "f16_mfma"))
+        pol = MlpPolicy(env.nS, env.nA, value_network=("shared" if actor == "f16_shared" else "copy")).to(dev)
+        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f32_mfma=(actor == "fp32_mfma"), f16_mfma=actor.startswith("f16"))
         adv, ret = torch.empty_like(ro.rew), torch.empty_like(ro.rew)
         sums = torch.zeros(2, dtype=torch.float64, device=dev)
         for _ in range(5):
@@ -919,6 +921,8 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
         nS, nA = env.nS, env.nA
         hbm_b = n * (T * (4 * (nS + nA + 1) + 1 + 8) + 8 * nS + 24 + 4)   # trajectory + logp + value per step; state etc. per launch
         useful = 2 * ((nS * 64 + 64 * 64 + 64 * nA) + (nS * 64 + 64 * 64 + 64))          # policy net + value net, per env-step
+        if actor == "f16_shared":
+            useful = 2 * (nS * 64 + 64 * 64 + 64 * (nA + 1))                              # one trunk, two heads
         roof = {"hbm": roofline_obj(hbm_b, ms_k, None, None,
                                     f"{n} envs x ({T} env-steps x {4 * (nS + nA + 1) + 1 + 8} B (actions, obs, reward, done, logp, value) + "
                                     f"{8 * nS + 28} B per launch)")}
@@ -926,7 +930,7 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
             # matrix-pipe work incl. tile padding: bf16 = 56 v_mfma_f32_32x32x16_bf16 per 64 envs and step (inputs padded 10 -> 16,
             # outputs 4 / 1 -> 32); fp32 = 2 nets x (2 ceil(nS / 2) + 64) v_mfma_f32_32x32x2_f32 per 32 envs (layer 3 on the vector ALU)
             half = actor != "fp32_mfma"                          # bf16 / f16 operands: the same instruction count and peak
-            padded = 56 * 2 * 32 * 32 * 16 / 64 if half else 2 * (2 * ((nS + 1) // 2) + 64) * 2 * 32 * 32 * 2 / 32
+            padded = (28 if actor == "f16_shared" else 56) * 2 * 32 * 32 * 16 / 64 if half else 2 * (2 * ((nS + 1) // 2) + 64) * 2 * 32 * 32 * 2 / 32
             peak = 2500.0 if half else 157.3   # dense TFLOP/s, /opt/skills/guides/MI355X_MICROARCH.md
             ach = padded * n * T / (ms_k * 1e-3) / 1e12
             roof["mfma"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,

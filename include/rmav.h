@@ -120,9 +120,15 @@ enum rmav_policy_precision {
     RMAV_POLICY_BF16_MFMA = 1,  /* bf16 operands, fp32 accumulate on the matrix cores */
     RMAV_POLICY_FP32_MFMA = 2,  /* fp32 operands and accumulate on the fp32-input matrix instructions: same precision
                                    class as RMAV_POLICY_FP32 (only the summation order differs), ~2x its speed */
-    RMAV_POLICY_F16_MFMA = 3    /* f16 operands (11-bit mantissa), fp32 accumulate, tanh folded into the next layer's weights
-                                   (csrc/rmav_policy_pair.hpp): the fastest actor and ~8x closer to the fp32 policy than bf16.
+    RMAV_POLICY_F16_MFMA = 3,   /* f16 operands (11-bit mantissa), fp32 accumulate, tanh folded into the next layer's weights
+                                   (csrc/rmav_policy_pair.hpp): ~8x closer to the fp32 policy than bf16 and faster.
                                    Weight buffer: rmav_pack_policy_f16 */
+    RMAV_POLICY_F16_SHARED = 4  /* a DIFFERENT architecture, same arithmetic as RMAV_POLICY_F16_MFMA: ONE 2x64 tanh trunk with a mean head
+                                   and a scalar value head on its latent - baselines' value_network = 'shared', what ppo2 builds for an env
+                                   type without a defaults entry (the native envs of gym_reinmav: env_type 'native'); the other precisions
+                                   evaluate a policy net and a separate value net (value_network = 'copy', baselines' MuJoCo default).
+                                   Weight buffer: rmav_policy_weight_count_shared() floats = ONE net of the bf16 fragment layout with
+                                   output rows 0..3 = the mean head, row 4 = the value head, then logstd [4]; built by rmav_pack_policy_f16 */
 };
 
 /* rmav_create flags */
@@ -284,6 +290,7 @@ int64_t rmav_policy_weight_count_bf16(void);
  * then logstd [4];  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h  (csrc/rmav_policy_mfma32.hpp explains why;
  * gym_reinmav_amd.ppo.pack_policy_weights_f32_mfma builds it). */
 int64_t rmav_policy_weight_count_f32_mfma(void);
+int64_t rmav_policy_weight_count_shared(void);   /* RMAV_POLICY_F16_SHARED */
 /* Builds such a weight buffer on the device in ONE launch on the handle's stream: with `flat` = the concatenation of the
  * n_params (<= 16) parameter tensors `params[k]` (DEVICE pointers in a HOST array; sizes[k] elements each) followed by zeros,
  * weights_out[i] = flat[idx_lo[i]] when idx_hi[i] < 0, else the two bf16 roundings of flat[idx_lo[i]] (low half) and
@@ -357,7 +364,8 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
  * same result.  Only a call that is ONE fused launch over all of the handle's envs takes the snapshot; if none happens
  * between _arm and _post (single-step launches incl. rmav_rollout(fused = 0), a sliced launch), or if another stepping
  * launch follows the one that took it, _post packs as usual.  The communicator stream's wait for the armed launch is
- * bounded: 2 s counted from the moment that launch BEGINS on the device (it may sit behind any amount of queued work first).
+ * bounded: 2 s counted from the moment that launch BEGINS on the device (it may sit behind any amount of queued work first;
+ * controller-driven rollouts of <= 131 072 envs publish no start word and are bounded by the waiter's overall 10 min only).
  * Past that the waiter poisons this rank's payload - return NaN, length -1 for each of its envs, on every rank - and the
  * collective is issued all the same, so no peer hangs; rmav_allgather_stats_wait (and _result, once the waiter has run)
  * return RMAV_ERR_TIMEOUT for THAT post only: later posts on the communicator are unaffected.  One armed exchange per handle

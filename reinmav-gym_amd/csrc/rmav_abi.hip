@@ -162,7 +162,7 @@ constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches bey
 template <int K, int MODE, int ST>
 int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     RolloutArgs a = a_in;
-    take_armed_exchange(h, a, 64);
+    take_armed_exchange(h, a, 64, publishes_start(MODE));
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
     static_assert(!is_policy(MODE), "the policy-in-kernel rollouts are launched from rmav_policy_abi.hip");
@@ -909,6 +909,7 @@ int64_t rmav_policy_weight_count(int kind) {
 
 int64_t rmav_policy_weight_count_bf16(void) { return MfmaLayout::TOTAL; }
 int64_t rmav_policy_weight_count_f32_mfma(void) { return Mfma32Layout::TOTAL; }
+int64_t rmav_policy_weight_count_shared(void) { return MfmaLayout::NET + 4; }
 
 static int pack_policy_impl(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
                             const int32_t *idx_hi, int64_t n_out, float *weights_out, bool f16) {
@@ -929,7 +930,9 @@ static int pack_policy_impl(rmav_handle h, int n_params, const float *const *par
     src.n = n_params;
     const dim3 grid((unsigned)((n_out + 255) / 256));
     if (f16) {
-        if (n_out != MfmaLayout::TOTAL) return rmav_fail(RMAV_ERR_INVALID, "n_out must be rmav_policy_weight_count_bf16() = %d", (int)MfmaLayout::TOTAL);
+        if (n_out != MfmaLayout::TOTAL && n_out != MfmaLayout::NET + 4)
+            return rmav_fail(RMAV_ERR_INVALID, "n_out must be rmav_policy_weight_count_bf16() = %d or rmav_policy_weight_count_shared() = %d",
+                             (int)MfmaLayout::TOTAL, (int)MfmaLayout::NET + 4);
         hipLaunchKernelGGL(k_pack_policy<true>, grid, dim3(256), 0, h->stream, src, idx_lo, idx_hi, n_out, weights_out, (int32_t)MfmaLayout::NET,
                            (int32_t)MfmaLayout::A2, (int32_t)MfmaLayout::A3, (int32_t)MfmaLayout::B1, -2.0f * kTanhScale, -2.0f);
     } else {
@@ -952,9 +955,8 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
                         float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
                         float *value_out, int precision) {
     CHECK_HANDLE(h);
-    if (precision != RMAV_POLICY_FP32 && precision != RMAV_POLICY_BF16_MFMA && precision != RMAV_POLICY_FP32_MFMA &&
-        precision != RMAV_POLICY_F16_MFMA)
-        return rmav_fail(RMAV_ERR_INVALID, "precision must be RMAV_POLICY_FP32, RMAV_POLICY_BF16_MFMA, RMAV_POLICY_FP32_MFMA or RMAV_POLICY_F16_MFMA");
+    if (precision < RMAV_POLICY_FP32 || precision > RMAV_POLICY_F16_SHARED)
+        return rmav_fail(RMAV_ERR_INVALID, "precision must be one of RMAV_POLICY_FP32 ... RMAV_POLICY_F16_SHARED (rmav_policy_precision)");
     if (n_steps <= 0) return rmav_fail(RMAV_ERR_INVALID, "n_steps must be > 0");
     if (!weights || !logp_out || !value_out)
         return rmav_fail(RMAV_ERR_INVALID, "weights, logp_out and value_out are required (device pointers)");
@@ -972,6 +974,7 @@ int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, fl
     const int kmode = precision == RMAV_POLICY_FP32        ? (int)RMAV_ACT_POLICY
                       : precision == RMAV_POLICY_BF16_MFMA ? (int)RMAV_ACT_POLICY_BF16
                       : precision == RMAV_POLICY_F16_MFMA  ? (int)ACT_POLICY_F16
+                      : precision == RMAV_POLICY_F16_SHARED ? (int)ACT_POLICY_F16_SHARED
                                                            : (int)ACT_POLICY_F32M;
     h->xchg.allow = true;
     if (int rc = rmav_launch_policy_rollout(h, kmode, a)) return rc;
@@ -1505,8 +1508,8 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
         // rank's payload, notes the post number in the pair's time-out word and lets the gather go ahead - the peers get their
         // collective either way, and only THIS post reports RMAV_ERR_TIMEOUT.
         hipLaunchKernelGGL(k_wait_arrivals, dim3(1), dim3(256), 0, c->stream, (const uint32_t *)c->arrive, h->xchg.expected,
-                           h->xchg.seq, (const uint32_t *)c->started, kArrivalWaitTicks, kArrivalTotalTicks, c->timeout_seq_dev + k, c->send[k],
-                           cmax);
+                           h->xchg.seq, h->xchg.no_start ? (const uint32_t *)nullptr : (const uint32_t *)c->started, kArrivalWaitTicks,
+                           kArrivalTotalTicks, c->timeout_seq_dev + k, c->send[k], cmax);
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,

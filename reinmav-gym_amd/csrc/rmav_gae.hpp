@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void k_wait_arrivals(const uint32_t *arrive, u
             ok &= (int32_t)(__hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0;
         if (__syncthreads_and(ok)) break;
         const unsigned long long now = wall_clock64();
-        const int begun = __syncthreads_or((int32_t)(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0);
+        // (started == nullptr: a kernel family that publishes no start word - only the overall bound applies)
+        const int begun = started ? __syncthreads_or((int32_t)(__hip_atomic_load(started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - seq) >= 0) : 0;
         // (signed differences: the threads read the clock a few ticks apart, and an unsigned `now - t_start` of a thread that read
         // it just BEFORE the one whose reading became t_start would wrap around to "expired")
         int expired = (long long)(now - t0) > (long long)total_ticks;

@@ -72,6 +72,7 @@ struct rmav_env_s {
         bool armed, fired;
         bool allow;   // the call in progress is ONE fused launch over all envs (set by rollout_impl / rmav_rollout_policy)
         bool stale;   // another stepping launch followed the one that took the snapshot: _post must pack again
+        bool no_start;   // the launch that took it does not publish a start word (rmav::publishes_start): bounded by the overall limit only
         struct rmav_comm_s *comm;
         int slot;
         int64_t cmax;
@@ -119,7 +120,7 @@ inline dim3 grid_for(rmav_handle h) { return dim3((unsigned)((h->n + block_size(
 // whose first launch would snapshot the statistics T - 1 steps early, and not a sliced launch).  Any later stepping
 // launch makes that snapshot stale, and _post then packs afresh.  envs_per_word: envs behind one arrival word (64; 32 for
 // the fp32-MFMA actor's half-wavefront layout).
-inline void take_armed_exchange(rmav_handle h, rmav::RolloutArgs &a, int envs_per_word) {
+inline void take_armed_exchange(rmav_handle h, rmav::RolloutArgs &a, int envs_per_word, bool publishes_start = true) {
     if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;
     if (h->xchg.armed && !h->xchg.fired && h->xchg.allow && a.slice_count == 0 && (a.flags & rmav::F_TRACK)) {
         rmav_comm_s *c = h->xchg.comm;
@@ -130,6 +131,7 @@ inline void take_armed_exchange(rmav_handle h, rmav::RolloutArgs &a, int envs_pe
         a.xstarted = c->started;
         h->xchg.expected = (uint32_t)((h->n + envs_per_word - 1) / envs_per_word);
         h->xchg.fired = true;
+        h->xchg.no_start = !publishes_start;
     }
 }
 
@@ -143,5 +145,5 @@ inline int check_rollout_launch(rmav_handle h, const rmav::RolloutArgs &a) {
 }
 
 // rmav_policy_abi.hip: launches rmav_rollout_policy's kernel for kmode = RMAV_ACT_POLICY | RMAV_ACT_POLICY_BF16 | ACT_POLICY_F32M |
-// ACT_POLICY_F16 on the handle's stream
+// ACT_POLICY_F16 | ACT_POLICY_F16_SHARED on the handle's stream
 RMAV_INTERNAL int rmav_launch_policy_rollout(rmav_handle h, int kmode, const rmav::RolloutArgs &a);

@@ -43,13 +43,17 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
               // internal: ACT_BUFFER with the memory wavefront prefetching the caller's actions into the hand-over tile
               ACT_BUFFER_SPLIT = 9,
               // the f16 matrix-core actor (RMAV_POLICY_F16_MFMA): only as an (actor, critic) wavefront pair, rmav_policy_pair.hpp
-              ACT_POLICY_F16 = 10 };
+              ACT_POLICY_F16 = 10,
+              // ... and the shared-trunk form (one net with a mean head and a value head: RMAV_POLICY_F16_SHARED)
+              ACT_POLICY_F16_SHARED = 11 };
 constexpr bool is_mfma_policy(int mode) { return mode == ACT_POLICY_BF16 || mode == ACT_POLICY_F32M; }
 constexpr bool is_policy(int mode) { return mode == ACT_POLICY || is_mfma_policy(mode); }
 constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT || mode == ACT_BUFFER_SPLIT; }
 // split modes whose memory wavefront hands actions TO the integrator (drawn, or fetched from the caller's buffer)
 constexpr bool split_feeds_actions(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_BUFFER_SPLIT; }
 constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
+// kernels whose first workgroup publishes "begun" for an armed statistics exchange (see the top of k_rollout)
+constexpr bool publishes_start(int mode) { return mode != ACT_CONTROLLER_SPLIT; }
 // Split modes: env-steps per hand-over, and the LDS words of the double-buffered tiles
 // (actions: helper -> integrator, only when the helper draws them; obs + reward + done [+ actions]: integrator -> helper)
 // 1: the tiles of 8 pairs take 70 KB (quad3d) instead of 136 KB of the CU's 160 KB, so a communication kernel's
@@ -305,8 +309,15 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         if (a.n_steps <= 0) return;
     }
 
-    if (a.xsend && blockIdx.x == 0 && threadIdx.x == 0)   // (before the split modes' memory wavefronts return)
-        __hip_atomic_store(a.xstarted, a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // armed statistics exchange: "this launch has begun" - the communicator stream's 2 s bound counts from here.  Not in the
+    // controller-driven two-wavefront kernels: their integrators (fp64 controller on the fp64 step, 124 - 128 registers) spill to
+    // scratch with one more live value up here, and the same store inside their memory wavefront makes hipcc wrap that wavefront's
+    // buffer accesses in waterfall loops (tests/test_resource_usage.py catches both); the host knows (kPublishesStart) and bounds
+    // those launches by the waiter's overall limit only.
+    if constexpr (publishes_start(MODE)) {
+        if (a.xsend && blockIdx.x == 0 && threadIdx.x == 0)
+            __hip_atomic_store(a.xstarted, a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 
     unsigned int fin_n = 0, fin_len = 0;
     float fin_ret = 0.0f;

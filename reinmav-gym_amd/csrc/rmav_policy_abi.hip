@@ -48,6 +48,21 @@ template <int K, int FMT> int launch_rollout_pair(rmav_handle h, const RolloutAr
     return check_rollout_launch(h, a);
 }
 
+// RMAV_POLICY_F16_SHARED: one trunk, both wavefronts of a pair evaluate it for one 32-env column tile each (k_rollout_pair_shared)
+template <int K> int launch_rollout_pair_shared(rmav_handle h, const RolloutArgs &a_in) {
+    RolloutArgs a = a_in;
+    take_armed_exchange(h, a, 64);
+    const typename Env<K>::P p = derive_env<K>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params);
+    const int forced = h->tune[RMAV_TUNE_PAIR_GROUP];
+    // measured (profiles/r04/actor_bench.txt): 65 536 envs 1 / 2 / 4 pairs per workgroup 20.8 / 21.5 / 20.4 G env-steps/s, 131 072: 19.9 / 25.9 / 26.1
+    const int g = (forced >= 1 && forced <= kPairGroupMax) ? forced : 2;
+    const int64_t per_wg = 64 * g;
+    hipLaunchKernelGGL((k_rollout_pair_shared<K>), dim3((unsigned)((h->n + per_wg - 1) / per_wg)), dim3(128 * g), shared_lds_bytes<K>(g),
+                       h->stream, a, p, pc);
+    return check_rollout_launch(h, a);
+}
+
 template <int K> int launch_policy_k(rmav_handle h, int kmode, const RolloutArgs &a) {
     switch (kmode) {
     case RMAV_ACT_POLICY: return launch_policy_1w<K, ACT_POLICY>(h, a);
@@ -55,6 +70,7 @@ template <int K> int launch_policy_k(rmav_handle h, int kmode, const RolloutArgs
         return h->tune[RMAV_TUNE_POLICY_PAIR] == 0 ? launch_policy_1w<K, ACT_POLICY_BF16>(h, a) : launch_rollout_pair<K, FMT_BF16>(h, a);
     case ACT_POLICY_F32M: return launch_policy_1w<K, ACT_POLICY_F32M>(h, a);
     case ACT_POLICY_F16: return launch_rollout_pair<K, FMT_F16>(h, a);
+    case ACT_POLICY_F16_SHARED: return launch_rollout_pair_shared<K>(h, a);
     }
     return rmav_fail(RMAV_ERR_INVALID, "unknown policy mode %d", kmode);
 }

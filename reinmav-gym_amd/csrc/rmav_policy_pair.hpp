@@ -454,4 +454,356 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     }
 }
 
+// ---- one shared 2 x 64 trunk with a mean head and a value head (RMAV_POLICY_F16_SHARED) -------------------------------------------
+//
+// baselines' build_policy(value_network=None) - what `python -m gym_reinmav.run --alg=ppo2 --network=mlp` builds for the NATIVE envs:
+// their env_type is 'native' (entry point gym_reinmav.envs.native:...), for which baselines' ppo2 has no defaults entry, so
+// value_network stays None = 'shared': the value function is a linear head on the policy's latent (run.py:63-68; third-party
+// behaviour restated from memory).  The MuJoCo defaults (value_network='copy': two separate nets) are what
+// k_rollout_pair above evaluates.  One net = half the activations (128 tanh per env and step instead of 256), and the pair splits
+// differently: both wavefronts evaluate the net, each for ONE 32-env column tile -
+//   A (wave 0): tile 0 = envs 0..31 from its registers;  then action = mean + std z, dynamics, bookkeeping for all 64 envs
+//   B (wave 1): tile 1 = envs 32..63 from the hand-over tile; hands the 32 means to A; noise one step ahead, log-prob, all stores
+// with two barriers per env-step (X: the means are there; Y: the step's outputs are there).  Output rows 0..3 of the padded
+// 32-row output tile are the action mean, row 4 the value: after the last MFMA the mean of env column n sits in lane n
+// (h = 0) and its value in lane 32 + n (h = 1), register 0 - for tile 0 that is already the lane that owns the env.
+template <int NS, int NA> struct SharedTile {
+    using PT = PairTile<NS, NA>;
+    static constexpr int MEAN = PT::WORDS;            // means of tile 1's envs [4][32], B -> A
+    static constexpr int WORDS = PT::WORDS + 4 * 32;
+};
+constexpr int kSharedWeights = MfmaLayout::NET + 4;   // one net + logstd[4]
+template <int K> constexpr size_t shared_lds_bytes(int g) {
+    return sizeof(float) * ((size_t)kSharedWeights + (size_t)g * SharedTile<Dims<K>::NS, Dims<K>::NA>::WORDS);
+}
+
+// the net for ONE column tile: o4 = registers 0..3 of the output accumulator (lanes h = 0: rows 0..3 = mean; h = 1: row 4 = value)
+__device__ __forceinline__ void mlp_half_f16(f16x8_t b_in, float (&o4)[4]) {
+    using L = MfmaLayout;
+    using O = PairOps<FMT_F16>;
+    uint32_t net = 0u;
+    asm volatile("" : "+v"(net));   // keep the weight reads inside the env-step loop
+    const float *w = lds_w + net;
+    const uint32_t lane = threadIdx.x & 63u, h = lane >> 5;
+    f32x16_t acc[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+        acc[T] = O::mfma(ld_frag_t<FMT_F16>(w + L::A1 + T * L::FRAG, lane), b_in, bias_frag(w + L::B1 + 32 * T, h));
+    f16x8_t hb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) hb[s] = act_frag_f16(acc[s >> 1], s & 1);
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+        acc[T] = bias_frag(w + L::B2 + 32 * T, h);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[T] = O::mfma(ld_frag_t<FMT_F16>(w + L::A2 + (T * 4 + s) * L::FRAG, lane), hb[s], acc[T]);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) hb[s] = act_frag_f16(acc[s >> 1], s & 1);
+    f32x16_t o = bias_frag(w + L::B3, h);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o = O::mfma(ld_frag_t<FMT_F16>(w + L::A3 + s * L::FRAG, lane), hb[s], o);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o4[r] = o[r];
+}
+
+__device__ __forceinline__ f16x8_t pack_frag_f16(const float (&v)[8]) {
+    typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+    u32x4_t pk;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pk[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(kTanhScale * v[2 * j], kTanhScale * v[2 * j + 1]));
+    return __builtin_bit_cast(f16x8_t, pk);
+}
+
+template <int K>
+__global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(const RolloutArgs a, const typename Env<K>::P p_shared,
+                                                                                 const ParamsT<double> pc_shared) {
+    constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
+    using L = MfmaLayout;
+    using PT = PairTile<NS, NA>;
+    using ST_ = SharedTile<NS, NA>;
+    const uint32_t G = blockDim.x >> 7;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool helper = wave >= G;
+    const uint32_t pair = helper ? wave - G : wave, lane = threadIdx.x & 63u, h = lane >> 5;
+    const uint32_t gi = (blockIdx.x * G + pair) * 64u + lane;
+    const int64_t n = a.n;
+    const bool valid = gi < (uint64_t)n;
+    const uint32_t li = valid ? gi : (uint32_t)n - 1u;
+    const uint32_t col = (uint32_t)n * 4u, off = li * 4u;
+    const int32_t T = a.n_steps;
+    const bool track = (a.flags & F_TRACK) != 0, auto_reset = (a.flags & F_AUTO_RESET) != 0;
+    float *tile = lds_w + kSharedWeights + pair * ST_::WORDS;
+    float *ztile = tile + lane, *otile = tile + PT::Z_WORDS + lane, *mtile = tile + ST_::MEAN;
+
+    if (a.xsend && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_store(a.xstarted, a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    {   // stage the one net (+ logstd: the buffer's last four words land where LOGSTD of a two-net buffer would not be: keep them apart)
+        const float4 *src = reinterpret_cast<const float4 *>(a.policy_w);
+        float4 *dst = reinterpret_cast<float4 *>(lds_w);
+        for (int q = threadIdx.x; q < kSharedWeights / 4; q += blockDim.x) dst[q] = src[q];
+        __syncthreads();
+        for (int q = threadIdx.x; q < 160; q += blockDim.x) {   // fold_biases_f16 for net 0 only
+            float *w = lds_w;
+            if (q < 64) {
+                w[L::B1 + q] *= kTanhScale;
+            } else {
+                const bool l2 = q < 128;
+                const int i = l2 ? q - 64 : q - 128, Tt = l2 ? (i >> 5) : 0, m = i & 31;
+                const float *frag0 = w + (l2 ? L::A2 + Tt * 4 * L::FRAG : L::A3);
+                float sum = 0.0f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const f16x8_t v = *reinterpret_cast<const f16x8_t *>(frag0 + s * L::FRAG + (m + 32 * hh) * 4);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) sum += (float)v[j];
+                    }
+                float *b = w + (l2 ? L::B2 : L::B3) + i;
+                *b = (l2 ? kTanhScale * *b : *b) - 0.5f * sum;
+            }
+        }
+        __syncthreads();
+    }
+    const float *logstd = lds_w + L::NET;
+    const uint64_t env_id = a.env_base + (uint64_t)li;
+
+    if (helper) {
+        // ---- B: tile 1 of the net, noise one step ahead, log-prob, every trajectory store ---------------------------------------
+        float sl = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) sl += logstd[c];
+        const float logp0 = -sl - 0.5f * (float)NA * 1.8378770664093453f;
+        float *logp_out = a.logp_out, *val_out = a.val_out;
+        auto draw = [&](int32_t k) {
+            float z[4];
+            gaussian4(a.seed, env_id, a.t0 + (uint64_t)k, z);
+            float *zt = ztile + (k & 1) * PT::Z_HALF;
+            float q = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) zt[c * 64] = z[c];
+#pragma unroll
+            for (int c = 0; c < NA; ++c) q = rfma(z[c], z[c], q);
+            buf_st(make_rsrc(logp_out), off, 0, rfma(-0.5f, q, logp0));
+            logp_out += n;
+        };
+        // the net for envs 32..63 of the pair from the obs tile half `half`: lane (n, h) takes components [8h, 8h + 8) of env 32 + n
+        auto eval_tile1 = [&](int half) {
+            const float *obs = tile + PT::Z_WORDS + half * PT::O_HALF + 32u + (lane & 31u);
+            float x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo = (j < NS) ? obs[j * 64] : 0.0f, hi = (8 + j < NS) ? obs[(8 + j) * 64] : 0.0f;
+                x[j] = h ? hi : lo;
+            }
+            float o4[4];
+            mlp_half_f16(pack_frag_f16(x), o4);
+            if (!h) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) mtile[c * 32 + lane] = o4[c];    // means of envs 32..63 -> A
+            } else {
+                buf_st(make_rsrc(val_out), off, 0, o4[0]);                    // lane 32 + n IS env 32 + n of the pair
+            }
+            val_out += n;
+        };
+        draw(0);
+        __syncthreads();                                                  // P: Z(0) and the initial obs are in the tiles
+        float *act_out = a.act_out, *obs_out = a.obs_out, *rew_out = a.rew_out;
+        uint8_t *done_out = a.done_out;
+        auto drain = [&](int half) {
+            const float *row = otile + half * PT::O_HALF;
+            float o[NS], av[NA];
+#pragma unroll
+            for (int c = 0; c < NS; ++c) o[c] = row[c * 64];
+            const float rw = row[PT::REW], dn = row[PT::DONE];
+#pragma unroll
+            for (int c = 0; c < NA; ++c) av[c] = row[PT::ACT + c * 64];
+            const rsrc_t rA = act_out ? make_rsrc(act_out) : make_rsrc_bounded(a.state, 0u);
+            const rsrc_t rO = obs_out ? make_rsrc(obs_out) : make_rsrc_bounded(a.state, 0u);
+            const rsrc_t rR = rew_out ? make_rsrc(rew_out) : make_rsrc_bounded(a.state, 0u);
+            const rsrc_t rD = done_out ? make_rsrc(done_out) : make_rsrc_bounded(a.state, 0u);
+#pragma unroll
+            for (int c = 0; c < NA; ++c) buf_st(rA, off, (uint32_t)c * col, av[c]);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) buf_st(rO, off, (uint32_t)c * col, o[c]);
+            buf_st(rR, off, 0, rw);
+            __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(dn != 0.0f ? 1 : 0), rD, li, 0, 0);
+            if (act_out) act_out += (int64_t)NA * n;
+            if (obs_out) obs_out += (int64_t)NS * n;
+            if (rew_out) rew_out += n;
+            if (done_out) done_out += n;
+        };
+        for (int32_t k = 0; k < T; ++k) {
+            eval_tile1((k - 1) & 1);                                      // obs before step k
+            __syncthreads();                                              // X(k): the means of envs 32..63 are in the tile
+            if (k > 0) drain((k - 1) & 1);
+            if (k + 1 < T) draw(k + 1);
+            __syncthreads();                                              // Y(k): step k's outputs are in the tile
+        }
+        eval_tile1((T - 1) & 1);                                          // bootstrap values of envs 32..63
+        drain((T - 1) & 1);
+        return;
+    }
+
+    // ---- A: tile 0 of the net from its registers, then action, dynamics, bookkeeping for all 64 envs -----------------------------
+    const rsrc_t r_state = make_rsrc(a.state);
+    float s[NS];
+#pragma unroll
+    for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
+    unsigned int fin_n = 0, fin_len = 0;
+    float fin_ret = 0.0f;
+    float er = 0.0f;
+    int32_t el = 0;
+    if (track) {
+        er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+        el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+    }
+    int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
+    uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+    typename Env<K>::P pl = p_shared;
+    if constexpr (K != REINMAV) {
+        if (a.pe[0] || a.pe[1] || a.pe[2]) {
+            const double m = a.pe[0] ? (double)a.pe[0][li] : (double)pc_shared.mass;
+            const double ml = a.pe[1] ? (double)a.pe[1][li] : (double)pc_shared.load_mass;
+            const double Lt = a.pe[2] ? (double)a.pe[2][li] : (double)pc_shared.L;
+            override_params(pl, m, ml, Lt);
+        }
+    }
+    const typename Env<K>::P &p = pl;
+    double tenv = 0.0;
+    if constexpr (K == REINMAV) tenv = a.env_time[li];
+    float spare[NS];
+    bool have_spare = false;
+    if (K != REINMAV && auto_reset && T >= 8) {
+        reset_state<K>(a.seed, env_id, rc, spare);
+        have_spare = true;
+    }
+    float pol_std[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NA; ++c) pol_std[c] = expf(logstd[c]);
+    // value of env gi - 32 (tile 0's column lane - 32) leaves through this lane
+    const bool vvalid = h && (uint64_t)(gi - 32u) < (uint64_t)n;
+    const uint32_t voff = (gi - 32u) * 4u;
+    float *val_out = a.val_out;
+    auto eval_tile0 = [&](float (&o4)[4]) {   // lane (n, h): components [8h, 8h + 8) of env n - its own for h = 0, lane n's for h = 1
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float lo = (j < NS) ? s[j] : 0.0f;
+            float hi = 0.0f;
+            if (8 + j < NS) hi = xor32(s[8 + j]);   // lanes 32..63 receive lane - 32's component 8 + j  (folded: NS is a constant)
+            x[j] = h ? hi : lo;
+        }
+        mlp_half_f16(pack_frag_f16(x), o4);
+        if (vvalid) buf_st(make_rsrc(val_out), voff, 0, o4[0]);
+        val_out += n;
+    };
+    {   // the initial obs of the pair's envs, for B's first evaluation: the obs half step "-1" would have written
+        float *row = otile + PT::O_HALF;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
+    }
+    __syncthreads();                                                      // P
+    for (int32_t k = 0; k < T; ++k) {
+        float o4[4];
+        eval_tile0(o4);
+        __syncthreads();                                                  // X(k)
+        float act[NA];
+        {
+            const float *zt = ztile + (k & 1) * PT::Z_HALF;
+#pragma unroll
+            for (int c = 0; c < NA; ++c) {
+                const float mean = h ? mtile[c * 32 + (lane & 31u)] : o4[c];
+                act[c] = rfma(pol_std[c], zt[c * 64], mean);
+            }
+        }
+        float dist = 0.0f, r;
+        bool done;
+        if constexpr (K == REINMAV) {
+            float fm0[4];
+            Env<K>::step(s, act, false, tenv, p, fm0);
+            done = true;
+            r = 90.0f;
+        } else {
+            Env<K>::step(s, act, p, dist, done);
+            r = -dist;
+            if (done) {
+                r = (sb < 0) ? 1.0f : 0.0f;
+                sb = (sb < 0) ? 0 : sb + 1;
+            }
+        }
+        if (track) {
+            er += r;
+            el += 1;
+            if (done) {
+                buf_st(make_rsrc(a.last_ret), off, 0, er);
+                buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                if (valid) {
+                    fin_n += 1;
+                    fin_len += (unsigned int)el;
+                    fin_ret += er;
+                }
+                er = 0.0f;
+                el = 0;
+            }
+        }
+        if (K != REINMAV && auto_reset) {
+            if (__ballot(done && !have_spare) != 0) {
+                if (done && !have_spare) reset_state<K>(a.seed, env_id, rc, spare);
+            }
+            if (done) {
+#pragma unroll
+                for (int c = 0; c < NS; ++c) s[c] = spare[c];
+                have_spare = false;
+                rc += 1;
+            }
+        }
+        float *row = otile + (k & 1) * PT::O_HALF;
+#pragma unroll
+        for (int c = 0; c < NS; ++c) row[c * 64] = s[c];
+        row[PT::REW] = r;
+        row[PT::DONE] = done ? 1.0f : 0.0f;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) row[PT::ACT + c * 64] = act[c];
+        __syncthreads();                                                  // Y(k)
+    }
+    {
+        float o4[4];
+        eval_tile0(o4);                                                   // bootstrap values of envs 0..31
+    }
+#pragma unroll
+    for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+    if (track) {
+        buf_st(make_rsrc(a.ep_ret), off, 0, er);
+        buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+    }
+    if constexpr (K == REINMAV) a.env_time[li] = tenv;
+    buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
+    buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
+    if (track && __ballot(fin_n != 0) != 0) {
+        Totals *slot = a.totals + (gi >> 6);
+        const unsigned int wn = wave_sum_x(fin_n);
+        const unsigned int wl = wave_sum_x(fin_len);
+        const float wr = wave_sum_x(fin_ret);
+        if (lane == 0) {
+            atomicAdd(&slot->episodes, (unsigned long long)wn);
+            atomicAdd(&slot->length_sum, (unsigned long long)wl);
+            atomicAdd(&slot->return_sum, (double)wr);
+        }
+    }
+    if (a.xsend) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (valid) {
+            const float lr = a.last_ret[li];
+            const int32_t ll = a.last_len[li];
+            __hip_atomic_store(a.xsend + li, __builtin_bit_cast(int32_t, lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.xsend + a.xcmax + li, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && valid) __hip_atomic_store(a.xarrive + (gi >> 6), a.xseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
 }  // namespace rmav

@@ -21,7 +21,7 @@ PARAM_MASS, PARAM_LOAD_MASS, PARAM_TETHER_LENGTH = 0, 1, 2
 HOST, DEVICE = 0, 1
 SOA, AOS = 0, 1
 ACT_BUFFER, ACT_RANDOM, ACT_CONTROLLER, ACT_POLICY, ACT_POLICY_BF16 = 0, 1, 2, 3, 4
-POLICY_FP32, POLICY_BF16_MFMA, POLICY_FP32_MFMA, POLICY_F16_MFMA = 0, 1, 2, 3
+POLICY_FP32, POLICY_BF16_MFMA, POLICY_FP32_MFMA, POLICY_F16_MFMA, POLICY_F16_SHARED = 0, 1, 2, 3, 4
 INT_EULER, INT_RK4 = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5
@@ -96,6 +96,7 @@ PROTOTYPES = {
     "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
     "rmav_policy_weight_count_bf16": (C.c_int64, []),
     "rmav_policy_weight_count_f32_mfma": (C.c_int64, []),
+    "rmav_policy_weight_count_shared": (C.c_int64, []),
     "rmav_pack_policy": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _vp, _vp, C.c_int64, _fp]),
     "rmav_pack_policy_f16": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), _vp, _vp, C.c_int64, _fp]),
     "rmav_rollout_policy": (C.c_int, [C.c_void_p, C.c_int32, _fp, _fp, _fp, _fp, _u8p, _fp, _fp, C.c_int]),

@@ -65,17 +65,24 @@ class _LinearFM(torch.autograd.Function):
 
 
 class MlpPolicy(torch.nn.Module):
-    """baselines ``mlp`` (2 x 64 tanh) Gaussian policy + separate value net, in feature-major form."""
+    """baselines ``mlp`` (2 x 64 tanh) Gaussian policy, in feature-major form.
 
-    def __init__(self, n_obs: int, n_act: int, hidden: int = 64, init_logstd: float = 0.0):
+    ``value_network``: ``'copy'`` (default) = a separate value net of the same shape - baselines' MuJoCo default and its classic
+    ``MlpPolicy``; ``'shared'`` = a scalar value head on the policy's latent - what baselines' ``build_policy`` does when
+    ``value_network`` is None, i.e. for an env type without a ppo2 defaults entry such as the native envs of gym_reinmav
+    (``run.py:63-68``; third-party behaviour restated from memory).  ``self.vf`` is then the one-layer head."""
+
+    def __init__(self, n_obs: int, n_act: int, hidden: int = 64, init_logstd: float = 0.0, value_network: str = "copy"):
         super().__init__()
+        assert value_network in ("copy", "shared")
+        self.shared = value_network == "shared"
         mk = lambda i, o: torch.nn.Linear(i, o)  # noqa: E731
         self.pi = torch.nn.ModuleList([mk(n_obs, hidden), mk(hidden, hidden), mk(hidden, n_act)])
-        self.vf = torch.nn.ModuleList([mk(n_obs, hidden), mk(hidden, hidden), mk(hidden, 1)])
+        self.vf = torch.nn.ModuleList([mk(hidden, 1)] if self.shared else [mk(n_obs, hidden), mk(hidden, hidden), mk(hidden, 1)])
         self.logstd = torch.nn.Parameter(torch.full((n_act,), float(init_logstd)))
         for net, last_gain in ((self.pi, 0.01), (self.vf, 1.0)):
             for i, lin in enumerate(net):
-                torch.nn.init.orthogonal_(lin.weight, gain=last_gain if i == 2 else math.sqrt(2.0))
+                torch.nn.init.orthogonal_(lin.weight, gain=last_gain if lin is net[-1] else math.sqrt(2.0))
                 torch.nn.init.zeros_(lin.bias)
 
     @staticmethod
@@ -87,8 +94,15 @@ class MlpPolicy(torch.nn.Module):
                 x = torch.tanh(x)
         return x
 
+    def _lin(self, lin, x):
+        return (_LinearFM.apply(x, lin.weight, lin.bias) if torch.is_grad_enabled() and x.is_cuda
+                else torch.addmm(lin.bias[:, None], lin.weight, x))
+
     def forward(self, obs_fm: torch.Tensor):
         """obs_fm [nS, N] -> (mean [nA, N], value [N])."""
+        if self.shared:
+            h = torch.tanh(self._lin(self.pi[1], torch.tanh(self._lin(self.pi[0], obs_fm))))
+            return self._lin(self.pi[2], h), self._lin(self.vf[0], h)[0]
         return self._mlp(self.pi, obs_fm), self._mlp(self.vf, obs_fm)[0]
 
     def log_prob(self, mean, act):
@@ -201,8 +215,13 @@ class _PolicyPacker:
         assert n_obs <= 16
         # f16: the bf16 fragment layout with f16 pairs (and the tanh fold's weight scales)
         self.f16 = bool(f16_mfma)
+        self.shared = bool(getattr(policy, "shared", False))
+        assert not self.shared or self.f16, "the shared-trunk policy runs on the f16 actor only (RMAV_POLICY_F16_SHARED)"
         self.policy, self.bf16, self.f32m = policy, bool(bf16_mfma) or self.f16, bool(f32_mfma)
         assert not (self.bf16 and self.f32m)
+        if self.shared:
+            self._init_shared(policy, n_obs)
+            return
         self.params = [policy.pi[0].weight, policy.pi[0].bias, policy.pi[1].weight, policy.pi[1].bias,
                        policy.pi[2].weight, policy.pi[2].bias, policy.vf[0].weight, policy.vf[0].bias,
                        policy.vf[1].weight, policy.vf[1].bias, policy.vf[2].weight, policy.vf[2].bias, policy.logstd]
@@ -277,12 +296,53 @@ class _PolicyPacker:
                 per_net = [1.0] * (2 * 64 * 8) + [-2.0 * self.K_TANH] * (8 * 64 * 8) + [-2.0] * (4 * 64 * 8)
                 self.frag_scale = torch.tensor(per_net + per_net, dtype=torch.float32, device=dev)
 
+    def _init_shared(self, policy, n_obs):
+        """ONE net in the bf16 fragment layout (include/rmav.h, RMAV_POLICY_F16_SHARED): output rows 0..3 of the padded 32-row output
+        tile = the mean head, row 4 = the value head; then logstd [4]."""
+        import numpy as np
+
+        self.params = [policy.pi[0].weight, policy.pi[0].bias, policy.pi[1].weight, policy.pi[1].bias, policy.pi[2].weight,
+                       policy.pi[2].bias, policy.vf[0].weight, policy.vf[0].bias, policy.logstd]
+        offs = np.cumsum([0] + [p.numel() for p in self.params])
+        ZERO, n_act = int(offs[-1]), policy.logstd.numel()
+        assert n_act <= 4
+
+        def W(k, r, c):
+            rows, cols = self.params[k].shape
+            return int(offs[k]) + r * cols + c if (r < rows and c < cols) else ZERO
+
+        def W3(m, c):      # padded output layer: rows 0 .. nA-1 the mean head, row 4 the value head
+            return W(4, m, c) if m < n_act else (W(6, 0, c) if m == 4 else ZERO)
+
+        fr = []
+        for Mt in range(2):
+            fr += [W(0, 32 * Mt + (l & 31), 8 * (l >> 5) + jj) for l in range(64) for jj in range(8)]
+        for Mt in range(2):
+            for s_ in range(4):
+                fr += [W(2, 32 * Mt + (l & 31), _rowmap(s_, l >> 5, jj)) for l in range(64) for jj in range(8)]
+        for s_ in range(4):
+            fr += [W3(l & 31, _rowmap(s_, l >> 5, jj)) for l in range(64) for jj in range(8)]
+        b3 = [int(offs[5]) + r if r < n_act else (int(offs[7]) if r == 4 else ZERO) for r in range(32)]
+        bias = [int(offs[1]) + r for r in range(64)] + [int(offs[3]) + r for r in range(64)] + b3
+        logstd = [int(offs[8]) + c if c < n_act else ZERO for c in range(4)]
+        dev = policy.logstd.device
+        self.idx_frag = torch.tensor(fr, dtype=torch.int64, device=dev)
+        self.idx_bias = torch.tensor(bias + logstd, dtype=torch.int64, device=dev)
+        self.n_frag, self.n_bias = len(fr) // 2, len(bias)
+        self.n_out = self.n_frag + self.n_bias + 4
+        per_net = [1.0] * (2 * 64 * 8) + [-2.0 * self.K_TANH] * (8 * 64 * 8) + [-2.0] * (4 * 64 * 8)
+        self.frag_scale = torch.tensor(per_net, dtype=torch.float32, device=dev)
+
     def native_maps(self):
         """(idx_lo, idx_hi) int32 device tensors of ``rmav_pack_policy``: output word i = flat[idx_lo[i]] (idx_hi[i] < 0) or the
         bf16 pair (flat[idx_lo[i]], flat[idx_hi[i]]); built once from the same index lists ``pack`` uses."""
         if getattr(self, "_native", None) is None:
             dev = self.params[0].device
-            if self.f32m or not self.bf16:
+            if self.shared:
+                fr, bi = self.idx_frag.to(torch.int32), self.idx_bias.to(torch.int32)
+                lo = torch.cat([fr[0::2], bi])
+                hi = torch.cat([fr[1::2], torch.full((bi.numel(),), -1, dtype=torch.int32, device=dev)])
+            elif self.f32m or not self.bf16:
                 lo = self.idx_f32.to(torch.int32)
                 hi = torch.full_like(lo, -1)
             else:
@@ -314,7 +374,10 @@ class _PolicyPacker:
     def pack(self, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in self.params] + [torch.zeros(1, device=self.params[0].device)])
-            if self.f32m or not self.bf16:
+            if self.shared:
+                fr = (flat[self.idx_frag] * self.frag_scale).to(torch.float16).view(torch.int16).view(torch.float32)
+                res = torch.cat([fr, flat[self.idx_bias]])
+            elif self.f32m or not self.bf16:
                 res = flat[self.idx_f32]
             else:
                 if self.f16:
@@ -367,6 +430,10 @@ class FusedPolicyCollector:
         import ctypes as C
 
         assert not (bf16_mfma and f16_mfma)
+        shared = bool(getattr(policy, "shared", False))
+        if shared:   # one trunk, two heads: RMAV_POLICY_F16_SHARED (the only actor of that architecture)
+            assert not bf16_mfma and not f32_mfma, "a shared-trunk policy runs on the f16 actor"
+            f16_mfma = True
         if f32_mfma is None:
             f32_mfma = not (bf16_mfma or f16_mfma)
 
@@ -385,7 +452,8 @@ class FusedPolicyCollector:
         self.val = torch.empty((T + 1, N), **f32)
         self.rew = torch.empty((T, N), **f32)
         self.done = torch.empty((T, N), dtype=torch.uint8, device=dev)
-        n_w = (A.lib().rmav_policy_weight_count_bf16() if (self.bf16_mfma or self.f16_mfma) else
+        n_w = (A.lib().rmav_policy_weight_count_shared() if shared else
+               A.lib().rmav_policy_weight_count_bf16() if (self.bf16_mfma or self.f16_mfma) else
                A.lib().rmav_policy_weight_count_f32_mfma() if self.f32_mfma else A.lib().rmav_policy_weight_count(env.kind))
         self.weights = torch.empty(n_w, **f32)
         assert self.weights.data_ptr() % 16 == 0
@@ -400,7 +468,7 @@ class FusedPolicyCollector:
         # (the env's handle is read at call time: env.close() clears it, and a cached copy would hand a freed handle to the library)
         self._call = (A.lib().rmav_rollout_policy, self.T, p(self.weights), p(self.act), p(self.obs[1:]), p(self.rew), p(self.done),
                       p(self.logp), p(self.val),
-                      A.POLICY_F16_MFMA if self.f16_mfma else A.POLICY_BF16_MFMA if self.bf16_mfma
+                      A.POLICY_F16_SHARED if shared else A.POLICY_F16_MFMA if self.f16_mfma else A.POLICY_BF16_MFMA if self.bf16_mfma
                       else A.POLICY_FP32_MFMA if self.f32_mfma else A.POLICY_FP32)
 
     def _pack(self):

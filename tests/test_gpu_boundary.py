@@ -214,6 +214,7 @@ for kind, n in (('quad3d', 4099), ('quad3d', 200000), ('quad2d_sl', 777), ('quad
         for kw in (dict(f32_mfma=False), dict(bf16_mfma=True), dict(f32_mfma=True), dict(f16_mfma=True)):
             col = FusedPolicyCollector(env, pol, 8, **kw)
             launches.append(col.collect)
+        launches.append(FusedPolicyCollector(env, MlpPolicy(env.nS, env.nA, value_network='shared').cuda(), 8).collect)   # shared trunk
     for fn in launches:
         A.check(L.rmav_allgather_stats_arm(env._h, comm, n))
         assert L.rmav_allgather_stats_arm(env._h, comm, n) == A.ERR_INVALID          # one at a time

@@ -231,12 +231,30 @@ def test_native_weight_pack_equals_the_torch_pack(G, kind):
             with torch.no_grad():                       # an optimiser step updates in place: the next pack must see it
                 for prm in pol.parameters():
                     prm.mul_(1.01).add_(0.003)
+    spol = MlpPolicy(env.nS, env.nA, init_logstd=-0.7, value_network="shared").cuda()   # one trunk, two heads: ONE net of fragments
+    with torch.no_grad():
+        for prm in spol.parameters():
+            prm.add_(torch.randn_like(prm) * 0.3)
+    pk = _PolicyPacker(spol, env.nS, False, f16_mfma=True)
+    ref = pk.pack()
+    out = torch.full_like(ref, float("nan"))
+    pk.pack_native(env, out)
+    env.sync()
+    torch.cuda.synchronize()
+    assert ref.numel() == G._abi.lib().rmav_policy_weight_count_shared() and torch.equal(out.view(torch.int32), ref.view(torch.int32))
     env.close()
 
 
 # tolerance of the matrix-core actors against the fp32 torch policy, relative to max(1, |y|): bf16 operands (8-bit mantissa)
 # 3e-2; f16 operands (11 bits) with tanh folded into the next layer 4e-3
-ACTOR_TOL = {"bf16": 3e-2, "bf16_1w": 3e-2, "f16": 4e-3}
+ACTOR_TOL = {"bf16": 3e-2, "bf16_1w": 3e-2, "f16": 4e-3, "f16_shared": 4e-3}
+
+
+def _policy_for(actor, n_obs, n_act, **kw):
+    """f16_shared: ONE trunk with a mean head and a value head (baselines' value_network='shared'); the others: two nets."""
+    from gym_reinmav_amd.ppo import MlpPolicy
+
+    return MlpPolicy(n_obs, n_act, value_network=("shared" if actor == "f16_shared" else "copy"), **kw)
 
 
 def _mfma_collector(G, env, pol, T, actor):
@@ -244,10 +262,10 @@ def _mfma_collector(G, env, pol, T, actor):
 
     if actor == "bf16_1w":   # round 3's one-wavefront-per-64-envs kernel (kept selectable)
         env.set_tuning(policy_pair=0)
-    return FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f16_mfma=(actor == "f16"))
+    return FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f16_mfma=actor.startswith("f16"))
 
 
-@pytest.mark.parametrize("actor", ["bf16", "bf16_1w", "f16"])
+@pytest.mark.parametrize("actor", ["bf16", "bf16_1w", "f16", "f16_shared"])
 @pytest.mark.parametrize("kind,n", [("quad3d", 512), ("quad3d_sl", 300), ("quad2d", 131), ("quad2d_sl", 65), ("reinmav", 64), ("quad3d", 1)])
 def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n, actor):
     """RMAV_POLICY_BF16_MFMA / RMAV_POLICY_F16_MFMA: the same two nets on the matrix cores (bf16 / f16 operands, fp32
@@ -264,10 +282,10 @@ def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n, actor):
     if kind == "reinmav":   # spread the envs out (they all start from the same init state)
         s0 = env.get_state() + np.random.RandomState(0).normal(scale=0.1, size=(n, 13)).astype(np.float32)
         env.set_state(s0)
-    pol = MlpPolicy(env.nS, env.nA, init_logstd=-1.0).cuda()
+    pol = _policy_for(actor, env.nS, env.nA, init_logstd=-1.0).cuda()
     with torch.no_grad():
         for net in (pol.pi, pol.vf):
-            net[2].weight.mul_(20.0 if net is pol.pi else 1.0)
+            net[-1].weight.mul_(20.0 if net is pol.pi else 1.0)
             for lin in net:
                 lin.bias.uniform_(-0.3, 0.3)
         pol.logstd.copy_(torch.linspace(-1.2, -0.4, env.nA))
@@ -337,6 +355,7 @@ def test_bf16_pair_kernel_equals_the_one_wavefront_kernel(G, kind, n):
 
 @pytest.mark.parametrize("actor,n,tune", [("bf16", 65536, {"pair_group": 1}), ("bf16", 65536, {"pair_group": 2}), ("bf16", 65536, {"pair_group": 4}),
                                            ("f16", 65536, {"pair_group": 2}), ("f16", 131072, {"pair_group": 2}), ("f16", 131072, {"pair_group": 4}),
+                                           ("f16_shared", 65536, {"pair_group": 1}), ("f16_shared", 65536, {"pair_group": 4}), ("f16_shared", 131072, {"pair_group": 2}),
                                            ("bf16_1w", 131072, {}), ("bf16_1w", 262144, {}), ("fp32_mfma", 65536, {}), ("fp32_mfma", 131072, {})])
 def test_matrix_core_actors_are_deterministic(G, actor, n, tune):
     """Every matrix-core actor, at 2 - 4 wavefronts per SIMD, five 32-step rollouts from the same state: bit-identical outputs.
@@ -354,7 +373,7 @@ def test_matrix_core_actors_are_deterministic(G, actor, n, tune):
         if tune:
             env.set_tuning(**tune)
         if pol is None:
-            pol = MlpPolicy(env.nS, env.nA, init_logstd=0.5).cuda()
+            pol = _policy_for(actor, env.nS, env.nA, init_logstd=0.5).cuda()
             with torch.no_grad():
                 pol.pi[2].weight.mul_(30.0)
                 pol.pi[2].bias.uniform_(0.5, 4.0)
@@ -373,7 +392,7 @@ def test_matrix_core_actors_are_deterministic(G, actor, n, tune):
         assert tot == tot0
 
 
-@pytest.mark.parametrize("actor", ["fp32", "fp32_mfma", "bf16", "f16"])
+@pytest.mark.parametrize("actor", ["fp32", "fp32_mfma", "bf16", "f16", "f16_shared"])
 def test_c5_size_policy_rollout(G, actor):
     """BASELINE configs[4] (C5)'s per-GPU shard at full size: quadrotor3d-v0, 65 536 envs x 32-step rollouts with the
     policy inside the kernel (fp32 and bf16-MFMA actors).  Every env step of a 4 096-env sample is checked against
@@ -385,14 +404,14 @@ def test_c5_size_policy_rollout(G, actor):
     torch.manual_seed(4)
     kind, N, T, seed = "quad3d", 65536, 32, 17
     env = G.BatchedQuadrotor(kind, N, seed=seed)
-    pol = MlpPolicy(env.nS, env.nA, init_logstd=0.5).cuda()
+    pol = _policy_for(actor, env.nS, env.nA, init_logstd=0.5).cuda()
     with torch.no_grad():
         pol.pi[2].weight.mul_(30.0)
         pol.pi[2].bias.uniform_(0.5, 4.0)          # thrust around hover, so episodes last a while and still end
-        pol.vf[2].bias.uniform_(-0.5, 0.5)
-    bf16 = actor in ("bf16", "f16")   # the reduced-precision actors
-    ro = FusedPolicyCollector(env, pol, T, bf16_mfma=(actor == "bf16"), f32_mfma=(actor == "fp32_mfma"), f16_mfma=(actor == "f16"))
-    assert ro.f32_mfma == (actor == "fp32_mfma") and ro.bf16_mfma == (actor == "bf16") and ro.f16_mfma == (actor == "f16")
+        pol.vf[-1].bias.uniform_(-0.5, 0.5)
+    bf16 = actor in ("bf16", "f16", "f16_shared")   # the reduced-precision actors
+    ro = FusedPolicyCollector(env, pol, T, bf16_mfma=(actor == "bf16"), f32_mfma=(actor == "fp32_mfma"), f16_mfma=actor.startswith("f16"))
+    assert ro.f32_mfma == (actor == "fp32_mfma") and ro.bf16_mfma == (actor == "bf16") and ro.f16_mfma == actor.startswith("f16")
     sample = np.arange(0, N, 16)                    # 4 096 envs, every wavefront represented
     rc = env.get_reset_counts()
     for it in range(2):

@@ -59,7 +59,7 @@ def test_two_wavefront_rollout_fits_1024_threads(usage, kind):
 
 
 def test_single_step_kernel_is_small(usage):
-    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav6k_stepILi2ELb0ELb0E")}
+    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav6k_stepILi2ELb0ELb0ELi0E")}   # (ST_DEFAULT: the shipped store policy)
     assert len(hits) == 1
     u = next(iter(hits.values()))
     assert u["vgpr"] <= 48 and u["occ"] == 8 and u["lds"] == 0, u
@@ -73,8 +73,8 @@ def test_fp32_mfma_actor_leaves_room_for_two_wavefronts_per_simd(usage):
 
 def test_pair_actors_fit_two_wavefronts_per_simd(usage):
     """k_rollout_pair<K, FMT_BF16 | FMT_F16>: at BASELINE's C5 shape every SIMD hosts two of these wavefronts: <= 256 registers."""
-    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav14k_rollout_pairILi")}
-    assert len(hits) == 10
+    hits = {n: v for n, v in usage.items() if n.startswith("_ZN4rmav14k_rollout_pairILi") or n.startswith("_ZN4rmav21k_rollout_pair_sharedILi")}
+    assert len(hits) == 15
     for n, u in hits.items():
         assert u["vgpr"] + u["agpr"] <= 256 and u["spill"] == 0 and u["scratch"] == 0 and u["occ"] >= 2, (n, u)
 
@@ -95,7 +95,7 @@ def test_matrix_core_kernels_have_no_lds_permutes_and_no_compiler_packed_fp32():
         seen += 1
         for bad in ("ds_bpermute", "ds_permute", "v_pk_mul_f32", "v_pk_mov_b32"):
             assert bad not in body, (name, bad)
-    assert seen >= 21, seen   # 10 pair kernels, 5 + 5 one-wavefront bf16 / fp32-MFMA kernels, mlp_mfma
+    assert seen >= 26, seen   # 10 + 5 pair kernels, 5 + 5 one-wavefront bf16 / fp32-MFMA kernels, mlp_mfma
     assert txt.count("v_permlane32_swap") >= 100 and txt.count("v_mfma_f32_32x32x16_f16") >= 100
 
 

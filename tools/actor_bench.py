@@ -9,7 +9,7 @@ import gym_reinmav_amd as g
 from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
 
 kind, T, iters = os.environ.get("KIND", "quad3d"), int(os.environ.get("T", "32")), int(os.environ.get("ITERS", "60"))
-variants = [("fp32_valu", {}), ("fp32_mfma", {}), ("bf16_1w", {"policy_pair": 0})] + [(a, {"pair_group": G}) for a in ("bf16", "f16") for G in (1, 2, 4)]
+variants = [("fp32_valu", {}), ("fp32_mfma", {}), ("bf16_1w", {"policy_pair": 0})] + [(a, {"pair_group": G}) for a in ("bf16", "f16", "f16_shared") for G in (1, 2, 4)]
 if os.environ.get("VARIANTS"):
     variants = [v for v in variants if v[0] in os.environ["VARIANTS"].split(",")]
 for n in [int(x) for x in os.environ.get("N", "65536").split(",")]:
@@ -18,8 +18,8 @@ for n in [int(x) for x in os.environ.get("N", "65536").split(",")]:
         env = g.BatchedQuadrotor(kind, n, seed=0, auto_reset=True, track_episodes=True)
         if tune:
             env.set_tuning(**tune)
-        pol = MlpPolicy(env.nS, env.nA).cuda()
-        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f16_mfma=(actor == "f16"), f32_mfma=(actor == "fp32_mfma"))
+        pol = MlpPolicy(env.nS, env.nA, value_network=("shared" if actor == "f16_shared" else "copy")).cuda()
+        ro = FusedPolicyCollector(env, pol, T, bf16_mfma=actor.startswith("bf16"), f16_mfma=actor.startswith("f16"), f32_mfma=(actor == "fp32_mfma"))
         for _ in range(5):
             ro.collect()
         torch.cuda.synchronize()

@@ -8,7 +8,7 @@ d = sys.argv[1]
 N, T = int(os.environ.get("N", "65536")), int(os.environ.get("T", "32"))
 ACTORS = collections.OrderedDict([   # kernel-name pattern -> label (quadrotor3d = kind 2)
     (r"k_rollout<2, 3, 0>", "fp32_valu"), (r"k_rollout<2, 8, 0>", "fp32_mfma"), (r"k_rollout<2, 4, 0>", "bf16_1w"),
-    (r"k_rollout_pair<2, 0>", "bf16_mfma"), (r"k_rollout_pair<2, 1>", "f16_mfma")])
+    (r"k_rollout_pair<2, 0>", "bf16_mfma"), (r"k_rollout_pair<2, 1>", "f16_mfma"), (r"k_rollout_pair_shared<2>", "f16_shared")])
 
 
 def label(kname):
@@ -39,7 +39,7 @@ print(f"# SQ counters of the policy-in-kernel rollouts (quadrotor3d, {N} envs x 
 # Vector-pipe model (tools/micro/issue_rate.hip, profiles/r04/issue_rate.md): cycles one wave64 instruction occupies the SIMD's vector
 # pipe with two or more wavefronts on it - transcendental 8.4, conversion / packed 4.45 - 5.0, anything else 2.8; a LONE wavefront
 # cannot issue faster than one instruction per 5.3 cycles (transcendental 8.8).  PACKED: static count of v_pk_* f32 per 64 envs·step.
-PACKED = {"fp32_valu": 0, "fp32_mfma": 0, "bf16_1w": 236, "bf16_mfma": 252, "f16_mfma": 130}
+PACKED = {"fp32_valu": 0, "fp32_mfma": 0, "bf16_1w": 236, "bf16_mfma": 252, "f16_mfma": 130, "f16_shared": 64}
 print("| actor | kernel us (trace) | per 64 envs·step: VALU | transcendental | convert | MFMA | SALU | LDS | VMEM wr | SIMD cycles per 64 envs·step | "
       "wavefront: issuing % | s_waitcnt / barrier % | issue-stall % | VALU busy per SIMD % | MFMA busy per SIMD % | vector-pipe model cycles | model / measured |")
 print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
