@@ -313,7 +313,7 @@ def test_bf16_mfma_actor_matches_fp32_policy(G, kind, n, actor):
         zp = _predicted_noise(seed, np.arange(n), t0 + t)[:, :env.nA]
         assert np.abs(z[:, t, :].T - zp).max() < tol * scale_m / float(std.min())
     logp_ref = -0.5 * torch.from_numpy(_predicted_noise(seed, np.arange(n), t0)[:, :env.nA] ** 2).sum(1) \
-        - float(pol.logstd.sum()) - 0.5 * env.nA * np.log(2 * np.pi)
+        - float(pol.logstd.detach().sum()) - 0.5 * env.nA * np.log(2 * np.pi)
     assert (ro.logp[0].cpu() - logp_ref).abs().max() < 1e-3
     assert np.array_equal(env.get_state(layout="soa"), ro.obs[T].cpu().numpy())
     env.close()

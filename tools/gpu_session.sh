@@ -11,6 +11,9 @@
 #   vecenv    bench.py's vecenv / gym1 legs only
 #   sq        SQ instruction / wait counters of the default bench command (EXTRA= adds bench arguments)
 #   prof      rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes of the bench cases -> summary.md, traffic.json
+#   actors    rocprofv3 trace + SQ counters of the policy-in-kernel rollouts (tools/profile_actors.sh)
+#   sqlegs    SQ counters of C3's shard and C4
+#   throttle  amd-smi throttle residencies around 6 s of each workload (tools/throttle_probe.sh)
 #   dist1     bench.py under torch.distributed.run with one rank (native exchange)
 TAG=${1:?tag}; shift
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
@@ -78,6 +81,16 @@ sq)
   ;;
 prof)
   bash tools/profile_round.sh $TAG ${ROUND:-r03} 2>&1 | tail -60
+  ;;
+actors)
+  bash tools/profile_actors.sh $TAG 2>&1 | tail -14
+  ;;
+sqlegs)   # SQ counters of C3's shard and of C4 (the default `sq` stage covers C2)
+  EXTRA="--envs-per-gpu 131072" bash tools/pmc_sq.sh $TAG/sq_c3shard > $OUT/sq_counters_c3shard.txt 2>&1; tail -32 $OUT/sq_counters_c3shard.txt
+  EXTRA="--kind quad3d_sl --envs-per-gpu 262144" bash tools/pmc_sq.sh $TAG/sq_c4 > $OUT/sq_counters_c4.txt 2>&1; tail -32 $OUT/sq_counters_c4.txt
+  ;;
+throttle)
+  bash tools/throttle_probe.sh $TAG 2>&1 | grep -E "^(rollout|memset|compute)" 
   ;;
 dist1)
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 1 --envs-per-gpu 131072 > $OUT/bench_torchrun1_c3shard.json 2> $OUT/bench_dist1.err; echo "rc=$?"; line $OUT/bench_torchrun1_c3shard.json

@@ -22,5 +22,5 @@ done
 cd $REPO
 python tools/parse_actor_profiles.py $OUT > $OUT/actors_sq.md; cat $OUT/actors_sq.md
 # keep the summaries, drop the bulky raw traces
-find $OUT -name "*.csv" -size +2M -delete
+find $OUT -name "*.csv" -size +8M -delete
 du -sh $OUT

@@ -25,6 +25,12 @@ CASES=(
   "c3shard_ring|--envs-per-gpu 131072 --steps 1000 --warmup 100"
   "c4_ring|--kind quad3d_sl --envs-per-gpu 262144 --steps 400 --warmup 50"
 )
+# the secondary legs whose kernels have no bench case of their own: C4 with per-env constants (k_rollout<3, 5, 1> of THIS run is that leg only),
+# ReinmavEnv (k_rollout<4, 2, 0>) and the policy-in-kernel rollouts of C5's per-GPU shape (k_rollout<2, 3|8|4, 0>, k_rollout_pair<2, *>,
+# k_rollout_pair_shared<2>) - traced under the driver's own command line, so that the averages are comparable with other_modes.*
+if [ -z "$ONLY" ] || [[ " $ONLY " =~ " legs " ]]; then
+  run trace_legs --kernel-trace --stats --output-format csv -d $OUT/trace_legs -- python $REPO/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary c4_pe,reinmav,policy
+fi
 for c in "${CASES[@]}"; do
   name=${c%%|*}; args=${c#*|}
   [ -n "$ONLY" ] && [[ ! " $ONLY " =~ " $name " ]] && continue
