@@ -355,6 +355,35 @@ template <> struct Env<QUAD3D_SL> {
     }
 };
 
+// sin and cos of the 2-D kinds' pitch angle (quadrotor2d.py:88, quadrotor2d_slungload.py:93: cos / sin of theta + pi/2).  libm's
+// sincosf is ~45 vector instructions; this one is ~25 (quadrotor2d 64-step launches at 65 536 envs 35.7 -> 35.0 us: the integrator wavefront's
+// instruction count is what its step time is made of at one pair per SIMD - a dependent chain issues as fast as an independent
+// one, profiles/r04/issue_rate.md - but the Philox draws and the hand-over are most of it): k = rint(x 2/pi), r = x - k pi/2 in two fma steps (pi/2 = HI + MID, products
+// exact inside the fma), 3-coefficient minimax polynomials in r^2 on [-pi/4, pi/4] (truncation 8e-9 / 6e-10), quadrant by bit
+// operations.  Absolute error <= 1.2e-7 for |x| < 32 768 (tests/test_hostmath.py vs libm's fp64); beyond that, and for inf / NaN,
+// libm (the angle is never wrapped, quirk Q9, but an env is long terminated before it gets there).
+RMAV_HD void fast_sincosf(float x, float &sn, float &cs) {
+    if (!(rabs(x) < 32768.0f)) {   // rare (and inf / NaN): the exact-reduction path of libm
+        sincosf(x, &sn, &cs);
+        return;
+    }
+    const float kf = __builtin_rintf(x * 0.63661977236758134f);
+    float r = rfma(kf, -1.5707963705062866f, x);
+    r = rfma(kf, 4.371138828673793e-08f, r);
+    const int32_t q = (int32_t)kf;
+    const float z = r * r;
+    const float ps = rfma(z, rfma(z, -1.9587950374e-04f, 8.3327488974e-03f), -1.6666664183e-01f);
+    const float pc = rfma(z, rfma(z, 2.4547991416e-05f, -1.3888303656e-03f), 4.1666664183e-02f);
+    const float s0 = rfma(r * z, ps, r);
+    const float c0 = rfma(z, rfma(z, pc, -0.5f), 1.0f);
+    // quadrant q & 3: (sin, cos) = (s, c), (c, -s), (-s, -c), (-c, s)
+    const bool swap = (q & 1) != 0;
+    const uint32_t sb = __builtin_bit_cast(uint32_t, swap ? c0 : s0) ^ (((uint32_t)q & 2u) << 30);
+    const uint32_t cb = __builtin_bit_cast(uint32_t, swap ? s0 : c0) ^ ((((uint32_t)q + 1u) & 2u) << 30);
+    sn = __builtin_bit_cast(float, sb);
+    cs = __builtin_bit_cast(float, cb);
+}
+
 // Quadrotor2D.step  quadrotor2d.py:74-113
 template <> struct Env<QUAD2D> {
     using R = float;
@@ -364,7 +393,7 @@ template <> struct Env<QUAD2D> {
         R thrust = p.thrust_scale * a[0];                         // :75
         if (p.clamp_thrust && thrust < R(0)) thrust = R(0);       // :76-77
         float sn, cs;
-        sincosf(s[2], &sn, &cs);
+        fast_sincosf(s[2], sn, cs);
         // (cos(th+pi/2), sin(th+pi/2)) = (-sin th, cos th)      :88
         const R k = thrust * p.inv_mass;
         const R acc[2] = {k * (-sn), rfma(k, cs, -p.g)};
@@ -395,7 +424,7 @@ template <> struct Env<QUAD2D_SL> {
         R thrust = p.thrust_scale * (R)a[0];                      // :80 (scale 1, no clamp by default)
         if (p.clamp_thrust && thrust < R(0)) thrust = R(0);
         float sn, cs;
-        sincosf(s[2], &sn, &cs);
+        sincosf(s[2], &sn, &cs);   // (fast_sincosf costs the controller-driven two-wavefront integrator of this kind a spill: resource test)
         const R dir[2] = {-(R)sn, (R)cs};
         const R tv[2] = {lp[0] - pos[0], lp[1] - pos[1]};         // :92
         const R dd = rfma(tv[0], tv[0], tv[1] * tv[1]);

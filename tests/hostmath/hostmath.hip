@@ -99,6 +99,9 @@ int hm_reset_state(int kind, uint64_t seed, uint64_t env, uint32_t idx, float *s
     }
     return 0;
 }
+void hm_fast_sincosf(int64_t n, const float *x, float *sn, float *cs) {   // the 2-D kinds' sin / cos
+    for (int64_t i = 0; i < n; ++i) fast_sincosf(x[i], sn[i], cs[i]);
+}
 double hm_fast_atan2(double y, double x) { return fast_atan2(y, x); }   // the 2-D controller's atan2 (host form: true division)
 int hm_random_action(int kind, uint64_t seed, uint64_t env, uint64_t t, float lo, float hi, float *a) {
     switch (kind) {

@@ -87,6 +87,32 @@ def test_rng_streams_bit_exact(hm, kind):
             assert np.array_equal(a, O.random_action(kind, 9, env, t, -10.0, 10.0))
 
 
+def test_fast_sincosf_vs_libm(hm):
+    """The 2-D kinds' sin / cos (two-fma reduction + 3-coefficient polynomials, csrc/rmav_math.hpp): absolute error <= 1.5e-7
+    against fp64 libm of the SAME fp32 argument over [-32768, 32768], dense near 0, at the multiples of pi/4 and their fp32
+    neighbours; beyond the range and for inf / NaN it must be libm itself.  (The step multiplies it by thrust / mass <= 100
+    and dt = 0.01: 1.5e-7 on the velocity, inside the 1e-6 bar with the rest of the step's rounding.)"""
+    rng = np.random.RandomState(1)
+    x = np.concatenate([rng.uniform(-4, 4, 400000), rng.uniform(-100, 100, 200000), rng.uniform(-32768, 32768, 400000),
+                        rng.uniform(-1e-3, 1e-3, 10000), np.arange(-2000, 2001) * (np.pi / 4)]).astype(np.float32)
+    x = np.concatenate([x, np.nextafter(x[-4001:], np.float32(np.inf)), np.nextafter(x[-4001:], np.float32(-np.inf)),
+                        np.array([0.0, -0.0, 32767.998, -32767.998], np.float32)])
+    sn, cs = np.empty_like(x), np.empty_like(x)
+    hm.hm_fast_sincosf(C.c_int64(len(x)), x.ctypes.data_as(FP), sn.ctypes.data_as(FP), cs.ctypes.data_as(FP))
+    xd = x.astype(np.float64)
+    es, ec = np.abs(sn - np.sin(xd)).max(), np.abs(cs - np.cos(xd)).max()
+    assert es <= 1.5e-7 and ec <= 1.5e-7, (es, ec)
+    assert np.abs(sn * sn + cs * cs - 1.0).max() <= 4e-7
+    big = np.array([32768.0, -1e6, 3.4e38, np.inf, -np.inf, np.nan], np.float32)
+    sb, cb = np.empty_like(big), np.empty_like(big)
+    hm.hm_fast_sincosf(C.c_int64(len(big)), big.ctypes.data_as(FP), sb.ctypes.data_as(FP), cb.ctypes.data_as(FP))
+    with np.errstate(invalid="ignore"):
+        ref_s, ref_c = np.sin(big.astype(np.float64)), np.cos(big.astype(np.float64))
+    assert np.array_equal(np.isnan(sb), np.isnan(ref_s)) and np.array_equal(np.isnan(cb), np.isnan(ref_c))
+    fin = np.isfinite(big)
+    assert np.abs(sb[fin] - ref_s[fin]).max() <= 1e-6 and np.abs(cb[fin] - ref_c[fin]).max() <= 1e-6
+
+
 def test_fast_atan2_vs_libm(hm):
     """The 2-D controller's atan2 (one reciprocal + an 8-coefficient polynomial, csrc/rmav_math.hpp): absolute error
     <= 1e-12 against libm over the plane, the axes, the octant boundaries and tiny / huge magnitudes (1e-11 would do:
