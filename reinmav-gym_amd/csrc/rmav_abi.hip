@@ -190,6 +190,8 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         // lean addressing in the memory wavefront: feature-major, every trajectory array below 4 GiB (32-bit scalar step offsets)
         if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * h->n < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
             a.flags |= F_LEAN;
+        // RMAV_TUNE_ROLE_SWAP = 1 + s: alternate the integrator / memory roles of the workgroup's halves by bit s of the workgroup index
+        if (const int rs = h->tune[RMAV_TUNE_ROLE_SWAP]; rs >= 1 && rs <= 4) a.flags |= F_ROLE_SWAP | ((uint32_t)(rs - 1) << 8);
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
                            lds_per_pair * g, h->stream, a, p, pc);
     } else {

@@ -112,7 +112,8 @@ template <int K, int MODE> constexpr int split_words_per_pair() {
 }
 // F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
 // memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
-enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u };
+// F_ROLE_SWAP (+ bits 8..9: which bit of the workgroup index alternates the roles): see the role assignment at the top of k_rollout
+enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u, F_ROLE_SWAP = 16u };
 
 
 struct Totals {
@@ -279,8 +280,15 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     [[maybe_unused]] constexpr int CH = SplitTile<NS, NA, DRAWS>::CH;   // env-steps per hand-over (split modes)
     // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
     const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
-    const bool split_helper = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
-    const uint32_t split_local = threadIdx.x - (split_helper ? 64u * split_g : 0u);
+    // Which wavefronts of the workgroup integrate and which move memory.  A workgroup's wavefronts go to consecutive SIMDs, so with
+    // ONE pair per workgroup (the latency-bound kinds) "wave 0 integrates" puts the integrators of a CU's four workgroups on SIMDs
+    // 0 and 2, two each, and their memory wavefronts on SIMDs 1 and 3 (SQ counters, quadrotor2d at 65 536 envs: every wavefront
+    // issues 48 % of its life and waits 45 %; 257 instructions per pair and step in 1 229 cycles).  F_ROLE_SWAP alternates the
+    // roles by bit `role_shift` of the workgroup index, so that every SIMD hosts one integrator and one memory wavefront.
+    const bool upper_half = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
+    const bool role_swap = SPLIT && (a.flags & F_ROLE_SWAP) != 0 && ((blockIdx.x >> ((a.flags >> 8) & 3u)) & 1u) != 0;
+    const bool split_helper = upper_half != role_swap;
+    const uint32_t split_local = threadIdx.x - (upper_half ? 64u * split_g : 0u);
     const uint32_t gi = a.slice_first + (SPLIT ? blockIdx.x * (64u * split_g) + split_local : blockIdx.x * blockDim.x + threadIdx.x);
     const uint32_t slice_end = a.slice_count ? a.slice_first + a.slice_count : (uint32_t)a.n;
     // SPLIT: this pair's hand-over tiles
@@ -596,7 +604,39 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         }
                         __syncthreads();                               // B1
                     }
-                    for (int32_t c = 2; c + 1 < nc; ++c) {             // steady state: no guards, no optional-output branches
+                    int32_t c = 2;
+                    if constexpr (DRAWS && action_pairs<K>()) {
+                        // One Philox block holds the actions of steps 2 j and 2 j + 1.  Written as `draw when t is even` inside
+                        // fill_l the compiler hoists the draw out of the branch and every step pays its 20 quarter-rate multiplies
+                        // (a third of the vector-pipe time of a 2-D pair): here the parity is in the structure of the loop instead.
+                        auto fill_half = [&](int32_t k, const uint32_t (&b)[4], uint32_t odd) {
+                            float *buf = lds_p + (k & 1) * ST_::A_HALF + lane;
+                            float act[NA];
+                            action_from_block<K>(b, (uint64_t)odd, a.act_lo, a.act_hi, act);
+#pragma unroll
+                            for (int q = 0; q < NA; ++q) buf[q * 64] = act[q];
+#pragma unroll
+                            for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(rA, voff[q], (uint32_t)k * sA, act[q]);
+                        };
+                        if (c + 1 < nc && ((a.t0 + (uint64_t)(c + 1)) & 1u) != 0) {   // reach an even step
+                            fill_l(c + 1);
+                            drain_l(c - 2);
+                            __syncthreads();                           // Bc
+                            ++c;
+                        }
+                        for (; c + 2 < nc; c += 2) {
+                            uint32_t b2[4];
+                            random_block<K>(a.seed, env_id, a.t0 + (uint64_t)(c + 1), b2);
+                            fill_half(c + 1, b2, 0u);
+                            drain_l(c - 2);
+                            __syncthreads();                           // Bc
+                            fill_half(c + 2, b2, 1u);
+                            drain_l(c - 1);
+                            __syncthreads();                           // B(c + 1)
+                        }
+                        blk_valid = false;
+                    }
+                    for (; c + 1 < nc; ++c) {                          // steady state: no guards, no optional-output branches
                         if constexpr (DRAWS) fill_l(c + 1);
                         drain_l(c - 2);
                         __syncthreads();                               // Bc
@@ -947,11 +987,14 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             }
             if (K != REINMAV && auto_reset) {
                 const bool rst = done;
-                // A lane that terminates again in the same launch has no spare left: draw one first.  Rare, and skipped with ONE
+                // A lane that terminates again in the same launch has no spare left: draw one first, skipped with ONE
                 // wave-uniform branch; what remains on the common path is a single predicated copy (the nested form - copy the
-                // spare OR draw - cost a dozen exec-mask instructions per step).
+                // spare OR draw - cost a dozen exec-mask instructions per step).  The draw costs the wavefront its ~130
+                // instructions whatever the number of lanes in it, so EVERY lane without a spare takes one then (its reset counter
+                // already names its next episode): one draw per wavefront serves all the lanes that have used theirs up, instead
+                // of one draw per second termination (the 2-D kinds under random actions: an on-demand draw in most steps).
                 if (__ballot(rst && !have_spare) != 0) {
-                    if (rst && !have_spare) {
+                    if (!have_spare) {
                         float sp[NS];
                         reset_state<K>(a.seed, env_id, rc, sp);
 #pragma unroll
@@ -959,6 +1002,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                             if constexpr (SPARE_LDS) lds_spare[c * 64] = sp[c];
                             else spare[c] = sp[c];
                         }
+                        have_spare = true;
                     }
                 }
                 if (rst) {

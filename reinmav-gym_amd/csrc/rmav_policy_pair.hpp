@@ -403,7 +403,10 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
         }
         if (K != REINMAV && auto_reset) {
             if (__ballot(done && !have_spare) != 0) {
-                if (done && !have_spare) reset_state<K>(a.seed, env_id, rc, spare);
+                if (!have_spare) {   // every lane that has used its spare up (see k_rollout)
+                    reset_state<K>(a.seed, env_id, rc, spare);
+                    have_spare = true;
+                }
             }
             if (done) {
 #pragma unroll
@@ -750,7 +753,10 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
         }
         if (K != REINMAV && auto_reset) {
             if (__ballot(done && !have_spare) != 0) {
-                if (done && !have_spare) reset_state<K>(a.seed, env_id, rc, spare);
+                if (!have_spare) {   // every lane that has used its spare up (see k_rollout)
+                    reset_state<K>(a.seed, env_id, rc, spare);
+                    have_spare = true;
+                }
             }
             if (done) {
 #pragma unroll

@@ -258,12 +258,15 @@ def test_fused_rollout_equals_single_steps(G, kind, mode, T):
     assert k0 == k1 == T
 
 
-@pytest.mark.parametrize("kind,n", [("quad3d_sl", 235931), ("quad2d_sl", 262144), ("quad3d", 131072 + 77)])
+@pytest.mark.parametrize("kind,n", [("quad3d_sl", 235931), ("quad2d_sl", 262144), ("quad3d", 131072 + 77), ("quad2d", 65536 + 13)])
 def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
     """One launch of the one-wavefront kernel, the two-wavefront kernel forced, and two rounds of it over balanced halves
     (the default for random-action slung-load batches of 1.75-2 x the capacity) write the same trajectory, state, reset
     counters and episode statistics - ragged sizes included.  The variant is an explicit per-handle override
-    (rmav_set_tuning), so all four run in this process."""
+    (rmav_set_tuning), so all of them run in this process.  The launches are 23, 64 and 24 steps long: the second and third
+    start at an odd and an even step (the memory wavefront of the 2-action kinds draws one Philox block per PAIR of steps and
+    has to find its parity), and quadrotor2d's episodes under random actions are short enough for second and third
+    terminations inside the 64-step launch (the batched refill of the spare reset states)."""
     import hashlib
 
     digests = {}
@@ -271,12 +274,14 @@ def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
                        ("two wavefronts, one launch", {"split": 1, "slice": 0}),
                        ("two wavefronts, sliced", {"slice": 1}),
                        ("two wavefronts, generic drain, 3 pairs per workgroup", {"split": 1, "slice": 0, "lean": 0, "split_group": 3}),
-                       ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0})):
+                       ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0}),
+                       ("two wavefronts, one pair per workgroup, roles alternating", {"split": 1, "slice": 0, "split_group": 1, "role_swap": 1}),
+                       ("two wavefronts, roles alternating by pairs of workgroups", {"split": 1, "slice": 0, "role_swap": 2})):
         env = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
         h = hashlib.sha256()
-        for _ in range(2):
-            tr = env.rollout(24, mode="random", layout="soa", want=("actions", "obs", "rew", "done"))
+        for T in (23, 64, 24):
+            tr = env.rollout(T, mode="random", layout="soa", want=("actions", "obs", "rew", "done"))
             for k in ("actions", "obs", "rew", "done"):
                 h.update(np.ascontiguousarray(tr[k]).tobytes())
         for a in (env.get_state(), env.get_sbd(), env.get_reset_counts()):
@@ -353,13 +358,15 @@ def test_single_step_variants_give_the_same_bits(G, kind):
 @pytest.mark.parametrize("kind", KINDS)
 def test_rollout_random_vs_oracle_teacher_forced(G, kind):
     """Random-action rollout with auto-reset: every step is checked against the oracle from the
-    device's own previous state; reset states and actions are bit-exact with the RNG specification."""
-    n, T, seed, base = 4096, 40, 11, 123456
+    device's own previous state; reset states and actions are bit-exact with the RNG specification.  64 steps: quadrotor2d's
+    envs terminate up to three or more times inside the launch (the spare reset state, then the batched refills of it)."""
+    n, T, seed, base = 4096, 64, 11, 123456
     lo, hi = BOX[kind]
     env = G.BatchedQuadrotor(kind, n, seed=seed, env_id_base=base, auto_reset=True, track_episodes=True)
     prev = env.get_state()
     sbd = env.get_sbd()
     rc = env.get_reset_counts().copy()
+    rc_start = rc.copy()
     tr = env.rollout(T, mode="random", layout="aos", fused=True, want=("actions", "obs", "rew", "done"))
     ids = base + np.arange(n)
     ret = np.zeros(n)
@@ -390,6 +397,8 @@ def test_rollout_random_vs_oracle_teacher_forced(G, kind):
         ln[dk] = 0
         prev = tr["obs"][k]
     assert np.array_equal(env.get_reset_counts(), rc)
+    if kind == "quad2d":
+        assert int((rc - rc_start).max()) >= 3, "the refill of a used-up spare reset state was not exercised"
     tot = env.episode_totals()
     assert tot["episodes"] == fin_n and tot["length_sum"] == fin_len
     assert abs(tot["return_sum"] - fin_ret) <= 1e-4 * max(1.0, abs(fin_ret))
