@@ -216,7 +216,8 @@ enum rmav_tuning_key {
     RMAV_TUNE_PAIR_GROUP = 12,     /* (actor, critic) wavefront pairs per workgroup of the matrix-core actors, 1 .. 4 */
     RMAV_TUNE_STEP_STORE = 13,     /* cache policy of k_step's per-env stores: 0 write-back (default), 1 write-through, 2 non-temporal */
     RMAV_TUNE_ROLE_SWAP = 14,      /* two-wavefront kernels: 1 + s = alternate which half of a workgroup integrates by bit s of the workgroup index */
-    RMAV_TUNE_COUNT = 15
+    RMAV_TUNE_FIXED_FLAGS = 15,    /* two-wavefront kernels: 0 = never take the variant with the usual launch options compiled in (bits are the same) */
+    RMAV_TUNE_COUNT = 16
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);

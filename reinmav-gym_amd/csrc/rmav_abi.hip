@@ -192,8 +192,15 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
             a.flags |= F_LEAN;
         // RMAV_TUNE_ROLE_SWAP = 1 + s: alternate the integrator / memory roles of the workgroup's halves by bit s of the workgroup index
         if (const int rs = h->tune[RMAV_TUNE_ROLE_SWAP]; rs >= 1 && rs <= 4) a.flags |= F_ROLE_SWAP | ((uint32_t)(rs - 1) << 8);
-        hipLaunchKernelGGL((k_rollout<K, MODE, ST>), dim3((unsigned)((count + per_wg - 1) / per_wg)), dim3(128 * g),
-                           lds_per_pair * g, h->stream, a, p, pc);
+        const dim3 grid((unsigned)((count + per_wg - 1) / per_wg)), block(128 * g);
+        bool launched = false;
+        if constexpr (ST == ST_WRITE_THROUGH) {   // the usual options, compiled in (k_rollout's FIXED)
+            if ((a.flags & (F_AOS | F_TRACK | F_AUTO_RESET)) == (F_TRACK | F_AUTO_RESET) && h->tune[RMAV_TUNE_FIXED_FLAGS] != 0) {
+                hipLaunchKernelGGL((k_rollout<K, MODE, ST, true>), grid, block, lds_per_pair * g, h->stream, a, p, pc);
+                launched = true;
+            }
+        }
+        if (!launched) hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid, block, lds_per_pair * g, h->stream, a, p, pc);
     } else {
         hipLaunchKernelGGL((k_rollout<K, MODE, ST>), grid_for(h), dim3(block_size(h)), lds, h->stream, a, p, pc);
     }

@@ -270,7 +270,13 @@ __device__ __forceinline__ void wide_cols(const float *tile, rsrc_t r, uint32_t 
     }
 }
 
-template <int K, int MODE, int ST = ST_DEFAULT>
+// FIXED: the launch's options are the usual ones - feature-major trajectories, episode statistics tracked, auto-reset - and known
+// at compile time.  The step loop tests each of them with a scalar compare + branch per env-step otherwise (loop-invariant, but the
+// compiler does not unswitch a loop of this size), and where a lone wavefront's issue rate IS the step time (one pair per SIMD:
+// ~5 cycles per instruction of any kind, profiles/r04/issue_rate.md) those ~10 instructions are 4-9 % of the launch
+// (65 536 envs: quadrotor3d 41.8 -> 40.2 us, quadrotor2d-slungload 42.3 -> 38.9, controller-driven quadrotor3d 52.4 -> 47.5).
+// Instantiated for the two-wavefront kernels with their default store policy; every other combination takes the runtime flags.
+template <int K, int MODE, int ST = ST_DEFAULT, bool FIXED = false>
 __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(const RolloutArgs a, const typename Env<K>::P p_shared,
                                                     const ParamsT<double> pc_shared) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
@@ -280,11 +286,10 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     [[maybe_unused]] constexpr int CH = SplitTile<NS, NA, DRAWS>::CH;   // env-steps per hand-over (split modes)
     // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
     const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
-    // Which wavefronts of the workgroup integrate and which move memory.  A workgroup's wavefronts go to consecutive SIMDs, so with
-    // ONE pair per workgroup (the latency-bound kinds) "wave 0 integrates" puts the integrators of a CU's four workgroups on SIMDs
-    // 0 and 2, two each, and their memory wavefronts on SIMDs 1 and 3 (SQ counters, quadrotor2d at 65 536 envs: every wavefront
-    // issues 48 % of its life and waits 45 %; 257 instructions per pair and step in 1 229 cycles).  F_ROLE_SWAP alternates the
-    // roles by bit `role_shift` of the workgroup index, so that every SIMD hosts one integrator and one memory wavefront.
+    // Which wavefronts of the workgroup integrate and which move memory.  F_ROLE_SWAP alternates the roles by bit `role_shift` of
+    // the workgroup index (a measurement knob: if a workgroup's wavefronts go to consecutive SIMDs, one pair per workgroup puts two
+    // integrators on SIMDs 0 and 2 of a CU and two memory wavefronts on 1 and 3).  Measured: no difference for any kind with one
+    // pair per workgroup, slower with several (profiles/r04/two_d_kinds.md) - which wavefronts share a SIMD is not what bounds them.
     const bool upper_half = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
     const bool role_swap = SPLIT && (a.flags & F_ROLE_SWAP) != 0 && ((blockIdx.x >> ((a.flags >> 8) & 3u)) & 1u) != 0;
     const bool split_helper = upper_half != role_swap;
@@ -306,9 +311,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     const uint32_t li = ((is_mfma_policy(MODE) || SPLIT) && !valid) ? slice_end - 1u : ge;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
-    const bool aos = (a.flags & F_AOS) != 0;
-    const bool track = (a.flags & F_TRACK) != 0;
-    const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
+    const bool aos = !FIXED && (a.flags & F_AOS) != 0;
+    const bool track = FIXED || (a.flags & F_TRACK) != 0;
+    const bool auto_reset = FIXED || (a.flags & F_AUTO_RESET) != 0;
 
     // (the host rejects n_steps <= 0; the two-wavefront barrier protocol below needs at least one step.  Only there:
     // the same guard in front of the one-wavefront variants made hipcc restructure their step loop and cost them

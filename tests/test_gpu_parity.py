@@ -276,7 +276,8 @@ def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
                        ("two wavefronts, generic drain, 3 pairs per workgroup", {"split": 1, "slice": 0, "lean": 0, "split_group": 3}),
                        ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0}),
                        ("two wavefronts, one pair per workgroup, roles alternating", {"split": 1, "slice": 0, "split_group": 1, "role_swap": 1}),
-                       ("two wavefronts, roles alternating by pairs of workgroups", {"split": 1, "slice": 0, "role_swap": 2})):
+                       ("two wavefronts, roles alternating by pairs of workgroups", {"split": 1, "slice": 0, "role_swap": 2}),
+                       ("two wavefronts, launch options read at run time", {"split": 1, "slice": 0, "fixed_flags": 0})):
         env = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
         h = hashlib.sha256()

@@ -26,9 +26,10 @@ def usage():
     return out
 
 
-def _k(usage, kind, mode, st):
-    hits = [v for n, v in usage.items() if n.startswith(f"_ZN4rmav9k_rolloutILi{kind}ELi{mode}ELi{st}E")]
-    assert len(hits) == 1, (kind, mode, st)
+def _k(usage, kind, mode, st, fixed=0):
+    """k_rollout<K, MODE, ST, FIXED> (FIXED: the usual launch options compiled in - two-wavefront kernels, ST_WRITE_THROUGH only)"""
+    hits = [v for n, v in usage.items() if n.startswith(f"_ZN4rmav9k_rolloutILi{kind}ELi{mode}ELi{st}ELb{fixed}E")]
+    assert len(hits) == 1, (kind, mode, st, fixed)
     return hits[0]
 
 
@@ -55,6 +56,9 @@ def test_two_wavefront_rollout_fits_1024_threads(usage, kind):
         assert u["vgpr"] <= 128 and u["spill"] == 0, (kind, st, u)
     for mode in (6, 9):            # controller-driven and caller-action variants: 8 pairs as well (round 3)
         u = _k(usage, kind, mode, 1)
+        assert u["spill"] == 0 and u["vgpr"] <= 128, (kind, mode, u)
+    for mode in (5, 6, 9):         # the same with the usual launch options compiled in (round 4)
+        u = _k(usage, kind, mode, 1, fixed=1)
         assert u["spill"] == 0 and u["vgpr"] <= 128, (kind, mode, u)
 
 
