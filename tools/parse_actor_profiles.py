@@ -7,7 +7,7 @@ import collections, csv, glob, json, os, re, sys
 d = sys.argv[1]
 N, T = int(os.environ.get("N", "65536")), int(os.environ.get("T", "32"))
 ACTORS = collections.OrderedDict([   # kernel-name pattern -> label (quadrotor3d = kind 2)
-    (r"k_rollout<2, 3, 0>", "fp32_valu"), (r"k_rollout<2, 8, 0>", "fp32_mfma"), (r"k_rollout<2, 4, 0>", "bf16_1w"),
+    (r"k_rollout<2, 3, 0,", "fp32_valu"), (r"k_rollout<2, 8, 0,", "fp32_mfma"), (r"k_rollout<2, 4, 0,", "bf16_1w"),
     (r"k_rollout_pair<2, 0>", "bf16_mfma"), (r"k_rollout_pair<2, 1>", "f16_mfma"), (r"k_rollout_pair_shared<2>", "f16_shared")])
 
 
