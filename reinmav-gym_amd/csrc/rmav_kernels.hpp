@@ -975,49 +975,102 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 act_out += (int64_t)NA * n;
             }
 
-            if (track) {
-                er += r;
-                el += 1;
-                if (done) {
-                    buf_st(make_rsrc(a.last_ret), off, 0, er);
-                    buf_st_i32(make_rsrc(a.last_len), off, 0, el);
-                    if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
-                        fin_n += 1;
-                        fin_len += (unsigned int)el;
-                        fin_ret += er;
-                    }
-                    er = 0.0f;
-                    el = 0;
+            // End of an episode (statistics) and auto-reset.  A lane that terminates again in the same launch has no spare reset
+            // state left: draw one first, skipped with ONE wave-uniform branch; what remains on the common path is a single predicated
+            // copy (the nested form - copy the spare OR draw - cost a dozen exec-mask instructions per step).  The draw costs the
+            // wavefront its ~130 instructions whatever the number of lanes in it, so EVERY lane without a spare takes one then (its
+            // reset counter already names its next episode): one draw per wavefront serves all the lanes that have used theirs up,
+            // instead of one draw per second termination (the 2-D kinds under random actions: an on-demand draw in most steps).
+            //
+            // Controller-driven and caller-action rollouts (SKIP_QUIET): all of it sits behind ONE more wave-uniform branch, and a
+            // step in which no lane of the wavefront finishes (every step of a hovering rollout) skips the ~25 predicated
+            // instructions of the episode hand-off and the reset copy: 65 536 envs, controller-driven, same box, quadrotor3d
+            // 47.4 -> 45.8 us, quadrotor2d 34.8 -> 31.2, quadrotor3d-slungload 71.5 -> 66.3.  Under random actions most wavefronts
+            // have a finishing lane in most steps and the extra branch costs 1-3 %, so there the block stays predicated.  (Two
+            // copies of the same statements rather than shared lambdas: the register allocation of the 1024-thread kernels
+            // is tight enough to spill with the latter - tests/test_resource_usage.py.)
+            constexpr bool SKIP_QUIET = MODE == ACT_CONTROLLER || MODE == ACT_CONTROLLER_SPLIT || is_buffer(MODE) || MODE == ACT_BUFFER_SPLIT;
+            if constexpr (SKIP_QUIET) {
+                if (track) {
+                    er += r;
+                    el += 1;
                 }
-            }
-            if (K != REINMAV && auto_reset) {
-                const bool rst = done;
-                // A lane that terminates again in the same launch has no spare left: draw one first, skipped with ONE
-                // wave-uniform branch; what remains on the common path is a single predicated copy (the nested form - copy the
-                // spare OR draw - cost a dozen exec-mask instructions per step).  The draw costs the wavefront its ~130
-                // instructions whatever the number of lanes in it, so EVERY lane without a spare takes one then (its reset counter
-                // already names its next episode): one draw per wavefront serves all the lanes that have used theirs up, instead
-                // of one draw per second termination (the 2-D kinds under random actions: an on-demand draw in most steps).
-                if (__ballot(rst && !have_spare) != 0) {
-                    if (!have_spare) {
-                        float sp[NS];
-                        reset_state<K>(a.seed, env_id, rc, sp);
+                if (__ballot(done) != 0) {
+                    if (track && done) {
+                        buf_st(make_rsrc(a.last_ret), off, 0, er);
+                        buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                        if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
+                            fin_n += 1;
+                            fin_len += (unsigned int)el;
+                            fin_ret += er;
+                        }
+                        er = 0.0f;
+                        el = 0;
+                    }
+                    if (K != REINMAV && auto_reset) {
+                        const bool rst = done;
+                        if (__ballot(rst && !have_spare) != 0) {
+                            if (!have_spare) {
+                                float sp[NS];
+                                reset_state<K>(a.seed, env_id, rc, sp);
+#pragma unroll
+                                for (int c = 0; c < NS; ++c) {
+                                    if constexpr (SPARE_LDS) lds_spare[c * 64] = sp[c];
+                                    else spare[c] = sp[c];
+                                }
+                                have_spare = true;
+                            }
+                        }
+                        if (rst) {
+#pragma unroll
+                            for (int c = 0; c < NS; ++c) {
+                                if constexpr (SPARE_LDS) s[c] = lds_spare[c * 64];
+                                else s[c] = spare[c];
+                            }
+                            have_spare = false;
+                            rc += 1;
+                        }
+                    }
+                }
+            } else {
+                if (track) {
+                    er += r;
+                    el += 1;
+                    if (done) {
+                        buf_st(make_rsrc(a.last_ret), off, 0, er);
+                        buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                        if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
+                            fin_n += 1;
+                            fin_len += (unsigned int)el;
+                            fin_ret += er;
+                        }
+                        er = 0.0f;
+                        el = 0;
+                    }
+                }
+                if (K != REINMAV && auto_reset) {
+                    const bool rst = done;
+                    if (__ballot(rst && !have_spare) != 0) {
+                        if (!have_spare) {
+                            float sp[NS];
+                            reset_state<K>(a.seed, env_id, rc, sp);
+#pragma unroll
+                            for (int c = 0; c < NS; ++c) {
+                                if constexpr (SPARE_LDS) lds_spare[c * 64] = sp[c];
+                                else spare[c] = sp[c];
+                            }
+                            have_spare = true;
+                        }
+                    }
+                    if (rst) {
 #pragma unroll
                         for (int c = 0; c < NS; ++c) {
-                            if constexpr (SPARE_LDS) lds_spare[c * 64] = sp[c];
-                            else spare[c] = sp[c];
+                            if constexpr (SPARE_LDS) s[c] = lds_spare[c * 64];
+                            else s[c] = spare[c];
                         }
-                        have_spare = true;
+                        have_spare = false;
+                        rc += 1;
                     }
-                }
-                if (rst) {
-#pragma unroll
-                    for (int c = 0; c < NS; ++c) {
-                        if constexpr (SPARE_LDS) s[c] = lds_spare[c * 64];
-                        else s[c] = spare[c];
-                    }
-                    have_spare = false;
-                    rc += 1;
                 }
             }
             if constexpr (SPLIT) {
