@@ -258,6 +258,17 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
                  float *actions_out, float *obs_out, float *rew_out, uint8_t *done_out, int mem,
                  int layout, int fused);
 
+/* rmav_rollout with a column pitch: device pointers, feature-major arrays whose feature columns are `pitch` elements apart -
+ * actions_in / actions_out [n_steps][nA][pitch], obs_out [n_steps][nS][pitch], rew_out / done_out [n_steps][pitch]; env i is
+ * element i of every column, elements [N, pitch) are never written.  Same results as rmav_rollout.  Why: with the plain layout
+ * a batch size that is not a multiple of 16 starts every column off a 64-byte line, every wavefront's 256-byte store ends in
+ * partial lines, and the library has to fall back to write-back stores (65 599 envs: 67.7 us per 64-step launch against 48.8
+ * for 65 600 on one box; 1 048 575: 1 564 against 730).  rmav_trajectory_pitch() = N rounded up to a multiple of 64 (so that
+ * the byte-wide done rows start on a line as well) takes the batch size out of it; any pitch >= N is accepted. */
+int64_t rmav_trajectory_pitch(rmav_handle h);
+int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
+                         float *obs_out, float *rew_out, uint8_t *done_out, int64_t pitch, int fused);
+
 /* PPO2-style rollout with the policy inside the kernel (the caller loop of gym_reinmav/run.py:63-68:
  * baselines ppo2 Runner = model.step(obs) -> env.step(actions), network='mlp').  Policy: two 64-unit tanh
  * layers -> Gaussian mean (state-independent log-std), plus a value net of the same shape.  All pointers

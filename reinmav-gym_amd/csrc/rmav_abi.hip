@@ -136,7 +136,7 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
     // 256-byte store ends in partial lines, and only the write-back L2 can merge them with the neighbouring wavefront's part -
     // write-through / non-temporal stores send the fragments on (same box: 65 599 envs 100.4 us per launch, write-back 67.7;
     // 131 071: 200.9 -> 116.5; 1 048 575: 1700 -> 1564; the aligned sizes next to them: 48.8, 90.8, 730).
-    if ((h->n & 15) != 0) return ST_DEFAULT;
+    if ((a.pitch & 15) != 0) return ST_DEFAULT;   // (rmav_rollout_pitched: the caller padded the columns, the batch size is free)
     if (split) return ST_WRITE_THROUGH;
     return bytes <= 192.0e6 ? ST_WRITE_THROUGH : ST_STREAM;
 }
@@ -188,7 +188,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;
         // lean addressing in the memory wavefront: feature-major, every trajectory array below 4 GiB (32-bit scalar step offsets)
-        if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * h->n < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
+        if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * a.pitch < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
             a.flags |= F_LEAN;
         // RMAV_TUNE_ROLE_SWAP = 1 + s: alternate the integrator / memory roles of the workgroup's halves by bit s of the workgroup index
         if (const int rs = h->tune[RMAV_TUNE_ROLE_SWAP]; rs >= 1 && rs <= 4) a.flags |= F_ROLE_SWAP | ((uint32_t)(rs - 1) << 8);
@@ -326,6 +326,7 @@ RolloutArgs base_args(rmav_handle h) {
     memset(&a, 0, sizeof(a));
     a.state = h->state;
     a.n = h->n;
+    a.pitch = h->n;
     a.sbd = h->sbd;
     a.reset_cnt = h->reset_cnt;
     a.ep_ret = h->ep_ret;
@@ -747,17 +748,19 @@ int rmav_reset(rmav_handle h, float *obs_out, int mem, int layout) {
 // call leaves behind, nA*N floats in `layout` (action_mode must be RMAV_ACT_BUFFER, n_steps 1).
 static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
                         float *obs_out, float *rew_out, uint8_t *done_out, float *ctrl_out, int mem, int layout,
-                        int fused) {
+                        int fused, int64_t pitch = 0) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, layout)) return rc;
     if (n_steps <= 0) return rmav_fail(RMAV_ERR_INVALID, "n_steps must be > 0");
+    if (pitch != 0 && (pitch < h->n || pitch > (int64_t)0x3fffffff || mem != RMAV_DEVICE || layout != RMAV_SOA))
+        return rmav_fail(RMAV_ERR_INVALID, "a column pitch must be in [num_envs, 2^30) and needs device pointers and the feature-major layout");
     if (action_mode < RMAV_ACT_BUFFER || action_mode > RMAV_ACT_CONTROLLER)
         return rmav_fail(RMAV_ERR_INVALID, "unknown action_mode %d", action_mode);
     if (action_mode == RMAV_ACT_BUFFER && !actions_in)
         return rmav_fail(RMAV_ERR_INVALID, "RMAV_ACT_BUFFER needs actions_in");
     if (ctrl_out && h->kind == RMAV_REINMAV)
         return rmav_fail(RMAV_ERR_INVALID, "ReinmavEnv's controller runs inside its step (the controller action mode); there is no separate control()");
-    const size_t n = (size_t)h->n, T = (size_t)n_steps;
+    const size_t n = pitch ? (size_t)pitch : (size_t)h->n, T = (size_t)n_steps;   // (the trajectory arrays' column pitch)
     const size_t nS = kStateDim[h->kind], nA = kActionDim[h->kind];
     const size_t b_act = T * nA * n * sizeof(float), b_obs = T * nS * n * sizeof(float);
     const size_t b_rew = T * n * sizeof(float), b_done = T * n, b_ctrl = nA * n * sizeof(float);
@@ -802,6 +805,7 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
 
     RolloutArgs a = base_args(h);
     if (layout == RMAV_AOS) a.flags |= F_AOS;
+    if (pitch) a.pitch = pitch;
     a.ctrl_out = d_ctrl;
     const int kmode = d_ctrl ? (int)ACT_BUFFER_CTRL : action_mode;
     // One wavefront, one k_step launch, outputs in the pinned block: the kernel publishes its completion in a pinned word and
@@ -889,6 +893,18 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
                  int layout, int fused) {
     return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, mem,
                         layout, fused);
+}
+
+int64_t rmav_trajectory_pitch(rmav_handle h) {
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid handle");
+    return (h->n + 63) & ~(int64_t)63;
+}
+
+int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
+                         float *obs_out, float *rew_out, uint8_t *done_out, int64_t pitch, int fused) {
+    if (pitch <= 0) return rmav_fail(RMAV_ERR_INVALID, "pitch must be > 0 (rmav_trajectory_pitch)");
+    return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE,
+                        RMAV_SOA, fused, pitch);
 }
 
 int rmav_step_control(rmav_handle h, const float *actions, float *obs_out, float *rew_out, uint8_t *done_out,

@@ -125,6 +125,8 @@ struct Totals {
 struct RolloutArgs {
     float *state;
     int64_t n;
+    int64_t pitch;          // elements between the feature columns of the trajectory arrays (act_in / act_out / obs_out [T][dim][pitch],
+                            // rew_out / done_out [T][pitch]): N, or rmav_rollout_pitched's; batch-major arrays always N
     const float *act_in;
     float *act_out;
     float *obs_out;
@@ -151,7 +153,7 @@ struct RolloutArgs {
     float *val_out;         // [n_steps + 1][N]
     float *ctrl_out;        // ACT_BUFFER_CTRL only: control() of the state after the last step, [nA][N] | [N][nA]
     // this launch covers envs [slice_first, slice_first + slice_count) of the handle's N (slice_count = 0: all of them);
-    // trajectory pitches stay N.  slice_first is a multiple of 64.
+    // trajectory pitches stay what they are.  slice_first is a multiple of 64.
     uint32_t slice_first, slice_count;
     // statistics exchange armed for this launch (rmav_allgather_stats_arm), nullptr otherwise: every wavefront snapshots
     // its envs' last-episode statistics into the exchange's send buffer [2][xcmax] and then publishes xseq in its word of
@@ -310,6 +312,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     const bool valid = ge < slice_end;
     const uint32_t li = ((is_mfma_policy(MODE) || SPLIT) && !valid) ? slice_end - 1u : ge;   // local env index
     const uint32_t col = (uint32_t)n * 4u;                      // bytes between components of an SoA block
+    // trajectory arrays: [T][dim][pitch] feature-major (rmav_rollout_pitched; pitch = N otherwise, and always for batch-major)
+    const int64_t tn = a.pitch;
+    const uint32_t tcol = (uint32_t)tn * 4u;
     const uint32_t off = li * 4u;                               // this lane's byte offset inside a column
     const bool aos = !FIXED && (a.flags & F_AOS) != 0;
     const bool track = FIXED || (a.flags & F_TRACK) != 0;
@@ -380,7 +385,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             const uint32_t aos_bytes = n_here * (uint32_t)(NS * 4);   // clones past the end of the batch store nothing
             // wave-uniform: the ragged last wavefront drains dword-wise, and so does a batch whose column pitch or done
             // pointer would misalign the 16-byte / packed-byte stores
-            [[maybe_unused]] const bool wide = !aos && n_here == 64u && (n & 3) == 0 &&
+            [[maybe_unused]] const bool wide = !aos && n_here == 64u && (tn & 3) == 0 &&
                                                (reinterpret_cast<uintptr_t>(a.done_out) & 3u) == 0;
             uint32_t aos_rd[NS];
 #pragma unroll
@@ -399,7 +404,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
 #pragma unroll
                         for (int q = 0; q < NA; ++q) buf[(j * NA + q) * 64] = act[q];
                         if (a.act_out) {
-                            float *dst_step = a.act_out + (int64_t)k * NA * n;
+                            float *dst_step = a.act_out + (int64_t)k * NA * tn;
                             if (aos) {
                                 float *dst = dst_step + (int64_t)li * NA;
 #pragma unroll
@@ -407,11 +412,11 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                             } else if (RMAV_WIDE_DRAIN && wide) {
                                 // the tile the integrator will read is also the transposition buffer (LDS executes one
                                 // wavefront's accesses in order)
-                                wide_cols<AUX, NA>(buf - lane + j * NA * 64, make_rsrc(dst_step), wave_first * 4u, col, lane);
+                                wide_cols<AUX, NA>(buf - lane + j * NA * 64, make_rsrc(dst_step), wave_first * 4u, tcol, lane);
                             } else {
                                 const rsrc_t ra = make_rsrc(dst_step);
 #pragma unroll
-                                for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * col, act[q]);
+                                for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * tcol, act[q]);
                             }
                         }
                     }
@@ -428,9 +433,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                             const float *row = tile + j * ST_::O_ROW;
                             if constexpr (!DRAWS) {
                                 if (a.act_out)
-                                    wide_cols<AUX, NA>(row + ST_::ACT, make_rsrc(a.act_out + (int64_t)k * NA * n), wave_first * 4u, col, lane);
+                                    wide_cols<AUX, NA>(row + ST_::ACT, make_rsrc(a.act_out + (int64_t)k * NA * tn), wave_first * 4u, tcol, lane);
                             }
-                            if (a.obs_out) wide_cols<AUX, NS>(row, make_rsrc(a.obs_out + (int64_t)k * NS * n), wave_first * 4u, col, lane);
+                            if (a.obs_out) wide_cols<AUX, NS>(row, make_rsrc(a.obs_out + (int64_t)k * NS * tn), wave_first * 4u, tcol, lane);
                         }
                     }
                     // reward and done of the chunk's CH steps in one instruction each: lanes [16 j, 16 j + 16) take step j
@@ -440,14 +445,14 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         const float *row = tile + sj * ST_::O_ROW;
                         if (a.rew_out) {
                             const float4 v = *reinterpret_cast<const float4 *>(row + ST_::REW + 4u * eq);
-                            buf_st4_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k0 * n), (wave_first + 4u * eq) * 4u + sj * col, 0u, v);
+                            buf_st4_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k0 * tn), (wave_first + 4u * eq) * 4u + sj * tcol, 0u, v);
                         }
                         if (a.done_out) {
                             const float4 d = *reinterpret_cast<const float4 *>(row + ST_::DONE + 4u * eq);
                             const uint32_t bytes = (d.x != 0.0f ? 1u : 0u) | (d.y != 0.0f ? 0x100u : 0u) | (d.z != 0.0f ? 0x10000u : 0u) |
                                                    (d.w != 0.0f ? 0x1000000u : 0u);
-                            __builtin_amdgcn_raw_buffer_store_b32(bytes, make_rsrc(a.done_out + (int64_t)k0 * n),
-                                                                  wave_first + 4u * eq + sj * (uint32_t)n, 0u, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(bytes, make_rsrc(a.done_out + (int64_t)k0 * tn),
+                                                                  wave_first + 4u * eq + sj * (uint32_t)tn, 0u, 0);
                         }
                     }
                     return;
@@ -459,7 +464,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         const float *row = buf + j * ST_::O_ROW;
                         if constexpr (!DRAWS) {
                             if (a.act_out) {
-                                float *dst_step = a.act_out + (int64_t)k * NA * n;
+                                float *dst_step = a.act_out + (int64_t)k * NA * tn;
                                 float av[NA];
 #pragma unroll
                                 for (int q = 0; q < NA; ++q) av[q] = row[ST_::ACT + q * 64];
@@ -470,12 +475,12 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                                 } else {
                                     const rsrc_t ra = make_rsrc(dst_step);
 #pragma unroll
-                                    for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * col, av[q]);
+                                    for (int q = 0; q < NA; ++q) buf_st_aux<AUX>(ra, off, (uint32_t)q * tcol, av[q]);
                                 }
                             }
                         }
                         if (a.obs_out) {
-                            float *dst_step = a.obs_out + (int64_t)k * NS * n;
+                            float *dst_step = a.obs_out + (int64_t)k * NS * tn;
                             float o[NS];
                             if (aos) {
                                 // batch-major: the integrator wrote [env][c]; read it back in output order, so the
@@ -495,13 +500,13 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
 #pragma unroll
                                 for (int q = 0; q < NS; ++q) o[q] = row[q * 64];
 #pragma unroll
-                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, off, (uint32_t)q * col, o[q]);
+                                for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(ro, off, (uint32_t)q * tcol, o[q]);
                             }
                         }
-                        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k * n), off, 0, row[ST_::REW]);
+                        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out + (int64_t)k * tn), off, 0, row[ST_::REW]);
                         if (a.done_out)
                             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row[ST_::DONE] != 0.0f ? 1 : 0),
-                                                                 make_rsrc(a.done_out + (int64_t)k * n), li, 0, 0);
+                                                                 make_rsrc(a.done_out + (int64_t)k * tn), li, 0, 0);
                     }
                 }
             };
@@ -517,12 +522,12 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 constexpr int NQ = NS > NA ? NS : NA;
                 uint32_t voff[NQ];
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) voff[q] = off + (uint32_t)q * col;
+                for (int q = 0; q < NQ; ++q) voff[q] = off + (uint32_t)q * tcol;
                 const rsrc_t rA = a.act_out ? make_rsrc(a.act_out) : make_rsrc_bounded(a.state, 0u);
                 const rsrc_t rO = a.obs_out ? make_rsrc(a.obs_out) : make_rsrc_bounded(a.state, 0u);
                 const rsrc_t rR = a.rew_out ? make_rsrc(a.rew_out) : make_rsrc_bounded(a.state, 0u);
                 const rsrc_t rD = a.done_out ? make_rsrc(a.done_out) : make_rsrc_bounded(a.state, 0u);
-                const uint32_t sA = (uint32_t)NA * col, sO = (uint32_t)NS * col, sR = col, sD = (uint32_t)n;
+                const uint32_t sA = (uint32_t)NA * tcol, sO = (uint32_t)NS * tcol, sR = tcol, sD = (uint32_t)tn;
                 auto drain_l = [&](int32_t k) {   // obs / reward / done (and the controller's action) of step k: LDS -> trajectory
                     const float *row = lds_p + ST_::A_WORDS + (k & 1) * ST_::O_HALF + lane;
                     float o[NS];
@@ -664,7 +669,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 float pre[D][NA];
                 auto issue = [&](int32_t k, float (&dst)[NA]) {
                     if (k < T) {
-                        const float *src_step = a.act_in + (int64_t)k * NA * n;
+                        const float *src_step = a.act_in + (int64_t)k * NA * tn;
                         if (aos) {
                             const float *src = src_step + (int64_t)li * NA;
 #pragma unroll
@@ -672,7 +677,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         } else {
                             const rsrc_t ri = make_rsrc(src_step);
 #pragma unroll
-                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(ri, off, (uint32_t)q * col);
+                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(ri, off, (uint32_t)q * tcol);
                         }
                     }
                 };
@@ -854,7 +859,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             } else {
                 const rsrc_t r = make_rsrc(src_step);
 #pragma unroll
-                for (int c = 0; c < NA; ++c) dst[c] = buf_ld(r, off, (uint32_t)c * col);
+                for (int c = 0; c < NA; ++c) dst[c] = buf_ld(r, off, (uint32_t)c * tcol);
             }
         };
         if constexpr (is_buffer(MODE)) load_actions(act_in, act_pre);
@@ -916,7 +921,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 // round trip per step (1.40 -> 1.26 us per env-step batch at 65 536 envs)
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = act_pre[c];
-                act_in += (int64_t)NA * n;
+                act_in += (int64_t)NA * tn;
                 if (k + 1 < a.n_steps) load_actions(act_in, act_pre);
             } else if constexpr (MODE == ACT_RANDOM) {
                 random_action<K>(a.seed, env_id, a.t0 + (uint64_t)k, a.act_lo, a.act_hi, act);
@@ -970,9 +975,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 } else {
                     const rsrc_t ra = make_rsrc(act_out);
 #pragma unroll
-                    for (int c = 0; c < NA; ++c) buf_st_aux<AUX>(ra, off, (uint32_t)c * col, act[c]);
+                    for (int c = 0; c < NA; ++c) buf_st_aux<AUX>(ra, off, (uint32_t)c * tcol, act[c]);
                 }
-                act_out += (int64_t)NA * n;
+                act_out += (int64_t)NA * tn;
             }
 
             // End of an episode (statistics) and auto-reset.  A lane that terminates again in the same launch has no spare reset
@@ -1119,17 +1124,17 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 } else {
                     const rsrc_t ro = make_rsrc(obs_out);
 #pragma unroll
-                    for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * col, s[c]);
+                    for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * tcol, s[c]);
                 }
-                obs_out += (int64_t)NS * n;
+                obs_out += (int64_t)NS * tn;
             }
             if (!SPLIT && rew_out) {
                 buf_st_aux<AUX>(make_rsrc(rew_out), off, 0, r);
-                rew_out += n;
+                rew_out += tn;
             }
             if (!SPLIT && done_out) {
                 __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(done_out), li, 0, 0);
-                done_out += n;
+                done_out += tn;
             }
         }
         if constexpr (MODE == ACT_CONTROLLER_SPLIT) __syncthreads();   // B(nc): the last step's outputs are in LDS
@@ -1292,6 +1297,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     // stay active, which the cooperative reset needs
     const uint32_t li = valid ? gi : (uint32_t)n - 1u;
     const uint32_t col = (uint32_t)n * 4u, off = li * 4u;
+    const uint32_t tcol = (uint32_t)a.pitch * 4u;   // trajectory columns (actions in, obs out): rmav_rollout_pitched
     const bool aos = (a.flags & F_AOS) != 0;
     const bool track = (a.flags & F_TRACK) != 0;
     const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     } else {
         const rsrc_t r = make_rsrc(a.act_in);
 #pragma unroll
-        for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * col);
+        for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * tcol);
     }
     float er = 0.0f;
     int32_t el = 0;
@@ -1406,7 +1412,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         } else {
             const rsrc_t ro = make_rsrc(a.obs_out);
 #pragma unroll
-            for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * col, s[c]);
+            for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * tcol, s[c]);
         }
     }
     if constexpr (CTRL) {   // control() of the state this launch leaves behind

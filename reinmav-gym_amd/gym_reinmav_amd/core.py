@@ -232,15 +232,41 @@ class BatchedQuadrotor:
         return x
 
     def rollout(self, n_steps: int, mode: str = "random", actions=None, layout: str = "soa", fused: bool = True,
-                want=("obs", "rew", "done"), device_out: bool = False, out: Optional[dict] = None) -> dict:
+                want=("obs", "rew", "done"), device_out: bool = False, out: Optional[dict] = None, pitched: Optional[bool] = None) -> dict:
         """Run ``n_steps`` steps of every env.  Returns a dict of the requested trajectories
-        (subset of 'actions', 'obs', 'rew', 'done').  ``out`` may carry preallocated buffers."""
+        (subset of 'actions', 'obs', 'rew', 'done').  ``out`` may carry preallocated buffers.
+
+        ``pitched`` (device, feature-major outputs that this call allocates): the arrays get a column pitch of
+        ``rmav_trajectory_pitch()`` = N rounded up to 64 and the results are ``[..., :N]`` views of them - same values, but a batch
+        size that is not a multiple of 16 keeps the fast store path (include/rmav.h: rmav_rollout_pitched).  Default: exactly
+        then.  Caller actions (``mode='buffer'``) and ``out`` buffers are plain ``[T, dim, N]`` arrays, so those calls are not pitched."""
         T = int(n_steps)
         m = _MODES[mode]
         a_in, mem = None, (A.DEVICE if device_out else A.HOST)
         if m == A.ACT_BUFFER:
             a_in, mem = self._in(actions, self._shape(self.nA, layout, T))
         dev = mem == A.DEVICE
+        can_pitch = dev and layout == "soa" and m != A.ACT_BUFFER and not out
+        if pitched is None:
+            pitched = can_pitch and self.num_envs % 16 != 0
+        elif pitched and not can_pitch:
+            raise ValueError("pitched=True needs device_out=True, layout='soa', in-kernel actions and no `out` buffers")
+        if pitched:
+            P = int(self._lib.rmav_trajectory_pitch(self._h))
+            if P < self.num_envs:
+                A.check(P)
+            full = {}
+            if "actions" in want:
+                full["actions"] = self._new((T, self.nA, P), np.float32, True)
+            if "obs" in want:
+                full["obs"] = self._new((T, self.nS, P), np.float32, True)
+            if "rew" in want:
+                full["rew"] = self._new((T, P), np.float32, True)
+            if "done" in want:
+                full["done"] = self._new((T, P), np.uint8, True)
+            A.check(self._lib.rmav_rollout_pitched(self._h, T, m, None, self._ptr(full.get("actions")), self._ptr(full.get("obs")),
+                                                   self._ptr(full.get("rew")), self._ptr(full.get("done")), P, 1 if fused else 0))
+            return {k: v[..., :self.num_envs] for k, v in full.items()}
         res = dict(out) if out else {}
         if "actions" in want and m != A.ACT_BUFFER and "actions" not in res:
             res["actions"] = self._new(self._shape(self.nA, layout, T), np.float32, dev)

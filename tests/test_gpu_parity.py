@@ -627,3 +627,69 @@ def test_full_size_yaw_equivariance(G, kind, n):
     ok = ~near & ~done
     assert np.abs(rew_r[ok] - rew[ok]).max() < 2e-6 * max(1.0, float(np.abs(rew[ok]).max()))
     env.close()
+
+
+@pytest.mark.parametrize("mode", ["random", "controller", "buffer"])
+@pytest.mark.parametrize("n,T,fused", [(63, 9, True), (4099, 24, True), (65599, 16, True), (131071, 12, True), (300007, 10, True), (4099, 5, False)])
+@pytest.mark.parametrize("kind", KINDS)
+def test_pitched_rollout_equals_the_plain_layout(G, kind, n, T, fused, mode):
+    """rmav_rollout_pitched (feature columns `pitch` elements apart, so that a batch size that is not a multiple of 16 keeps the
+    aligned store path) writes the same values as rmav_rollout, leaves elements [N, pitch) of every column alone, and leaves
+    the envs in the same state - every kernel family (two-wavefront, one-wavefront, single-step loop), caller actions included."""
+    import ctypes as C
+    import torch
+    from gym_reinmav_amd import _abi as A
+
+    nS, nA = NS[kind], NA[kind]
+    lo, hi = BOX[kind]
+    acts = None
+    if mode == "buffer":
+        acts = torch.empty((T, nA, n), device="cuda").uniform_(lo, hi, generator=torch.Generator(device="cuda").manual_seed(3))
+    ref_env = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
+    ref = ref_env.rollout(T, mode=mode, actions=acts, layout="soa", fused=fused, want=("actions", "obs", "rew", "done"),
+                          device_out=True, pitched=False)
+    env = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
+    P = int(env._lib.rmav_trajectory_pitch(env._h))
+    assert P % 64 == 0 and n <= P < n + 64
+    SENT = -12345.0
+    a_out = torch.full((T, nA, P), SENT, device="cuda")
+    obs = torch.full((T, nS, P), SENT, device="cuda")
+    rew = torch.full((T, P), SENT, device="cuda")
+    done = torch.full((T, P), 77, dtype=torch.uint8, device="cuda")
+    a_in = None
+    if mode == "buffer":
+        a_in = torch.full((T, nA, P), SENT, device="cuda")
+        a_in[..., :n] = acts
+    ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+    A.check(env._lib.rmav_rollout_pitched(env._h, T, {"buffer": A.ACT_BUFFER, "random": A.ACT_RANDOM, "controller": A.ACT_CONTROLLER}[mode],
+                                          ptr(a_in), None if mode == "buffer" else ptr(a_out), ptr(obs), ptr(rew), ptr(done), P, 1 if fused else 0))
+    torch.cuda.synchronize()
+    if mode != "buffer":
+        assert torch.equal(a_out[..., :n], ref["actions"]) and bool((a_out[..., n:] == SENT).all())
+    assert torch.equal(obs[..., :n], ref["obs"]) and bool((obs[..., n:] == SENT).all())
+    assert torch.equal(rew[..., :n], ref["rew"]) and bool((rew[..., n:] == SENT).all())
+    assert torch.equal(done[..., :n], ref["done"]) and bool((done[..., n:] == 77).all())
+    assert np.array_equal(env.get_state(), ref_env.get_state()) and np.array_equal(env.get_reset_counts(), ref_env.get_reset_counts())
+    assert env.episode_totals() == ref_env.episode_totals()
+    if mode != "buffer" and fused:   # the Python wrapper pitches by itself when N is not a multiple of 16
+        env2 = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
+        tr = env2.rollout(T, mode=mode, layout="soa", want=("actions", "obs", "rew", "done"), device_out=True)
+        assert tr["obs"].stride(-2) == P and all(torch.equal(tr[k], ref[k]) for k in ("actions", "obs", "rew", "done"))
+        env2.close()
+    env.close()
+    ref_env.close()
+
+
+def test_pitched_rollout_rejects_bad_arguments(G):
+    import torch
+    from gym_reinmav_amd import _abi as A
+
+    env = G.BatchedQuadrotor("quad3d", 1000, seed=1)
+    buf = torch.empty((4, 10, 1024), device="cuda")
+    with pytest.raises(A.RmavError):
+        A.check(env._lib.rmav_rollout_pitched(env._h, 4, A.ACT_RANDOM, None, None, buf.data_ptr(), None, None, 999, 1))
+    with pytest.raises(A.RmavError):
+        A.check(env._lib.rmav_rollout_pitched(env._h, 4, A.ACT_RANDOM, None, None, buf.data_ptr(), None, None, 0, 1))
+    with pytest.raises(ValueError):
+        env.rollout(4, mode="random", layout="aos", device_out=True, pitched=True)
+    env.close()
