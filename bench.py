@@ -7,7 +7,10 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 
 Workload (BASELINE.json configs): quadrotor3d-v0, random actions T~U[0,10), w~U[0,10)^3 drawn in-kernel from the
 counter RNG, auto-reset on done, episode tracking on.
   N = 1 : configs[1] (C2) - 65 536 envs on the GPU.
-  N > 1 : configs[2] (C3) - 131 072 envs per GPU, sharded by GLOBAL env id (N = 8 is exactly C3's 1 048 576 envs).
+  N > 1 : the same 65 536 envs on EVERY GPU, sharded by GLOBAL env id - weak scaling in the strict sense (per-GPU work fixed as N
+          grows; through round 3 the default for N > 1 was 131 072 per GPU, which compared a different per-GPU workload with N = 1's).
+          configs[2] (C3: 1 048 576 envs over 8 GPUs) is ``--gpus 8 --envs-per-gpu 131072``; its per-GPU kernel is also the
+          ``c3_shard`` leg of every N = 1 line.
 One bench "step" = ONE launch of the hot-path kernel over the rank's whole shard:
 
   --mode rollout (default): the fused rollout kernel advances every env ``--chunk`` (64) env-steps with the
@@ -253,7 +256,7 @@ def main():
                     help="action source of the fused rollout (controller = the reference's built-in / geometric controller; "
                          "buffer = caller-provided actions, read from a ring of [chunk][nA][N] device buffers)")
     ap.add_argument("--envs-per-gpu", type=int, default=None,
-                    help="default: 65536 on one GPU (BASELINE C2), 131072 per GPU on several (C3's shard)")
+                    help="default: 65536 per GPU (BASELINE C2 on one GPU; the same shard on every GPU of a multi-GPU run); 131072 = C3's shard")
     ap.add_argument("--mode", default="rollout", choices=["rollout", "step"])
     ap.add_argument("--chunk", type=int, default=64,
                     help="env-steps per launch in rollout mode (64 amortises the ~4.5 us fixed cost of a launch; "
@@ -304,7 +307,7 @@ def main():
 
     torch.manual_seed(0)  # the step mode's action ring is filled by torch's generator
     kind = args.kind
-    n = args.envs_per_gpu if args.envs_per_gpu else (65536 if world == 1 else 131072)
+    n = args.envs_per_gpu if args.envs_per_gpu else 65536
     n_total = n * world
     A = g._abi
     K_ = A.KIND_BY_NAME[kind]
@@ -584,6 +587,7 @@ def main():
 
     if rank == 0:
         cfg_name = ("BASELINE configs[1] (C2)" if (world == 1 and n == 65536 and kind == "quad3d") else
+                    f"BASELINE configs[1]'s 65 536 envs on each of {world} GPUs (weak scaling)" if (n == 65536 and kind == "quad3d") else
                     f"BASELINE configs[2] (C3: {n_total} envs over {world} GPUs)" if (n == 131072 and kind == "quad3d" and world == 8) else
                     "BASELINE configs[2]'s per-GPU shard (131 072 envs per GPU)" if (n == 131072 and kind == "quad3d") else
                     "BASELINE configs[3] (C4)" if (world == 1 and n == 262144 and kind == "quad3d_sl") else "custom")
