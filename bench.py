@@ -9,8 +9,9 @@ counter RNG, auto-reset on done, episode tracking on.
   N = 1 : configs[1] (C2) - 65 536 envs on the GPU.
   N > 1 : the same 65 536 envs on EVERY GPU, sharded by GLOBAL env id - weak scaling in the strict sense (per-GPU work fixed as N
           grows; through round 3 the default for N > 1 was 131 072 per GPU, which compared a different per-GPU workload with N = 1's).
-          configs[2] (C3: 1 048 576 envs over 8 GPUs) is ``--gpus 8 --envs-per-gpu 131072``; its per-GPU kernel is also the
-          ``c3_shard`` leg of every N = 1 line.
+          configs[2] (C3: 1 048 576 envs over 8 GPUs) is measured beside it in the same run: ``other_modes.c3`` = 131 072 envs on
+          every rank (N = 8: exactly C3), barrier-bracketed, slowest rank counts; ``--gpus 8 --envs-per-gpu 131072`` makes it the
+          headline instead, and its per-GPU kernel is also the ``c3_shard`` leg of every N = 1 line.
 One bench "step" = ONE launch of the hot-path kernel over the rank's whole shard:
 
   --mode rollout (default): the fused rollout kernel advances every env ``--chunk`` (64) env-steps with the
@@ -187,7 +188,7 @@ def roofline_obj(bytes_launch: float, launch_ms: float, traffic, traffic_src, de
 
 
 def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, label: str, tune=None, per_env_params=False,
-                cpu_seconds: float = 0.0):
+                cpu_seconds: float = 0.0, env_id_base: int = 0, before_timed=None):
     """One more single-GPU BASELINE config as its own short measurement: fused random-action rollouts of `kind` over `n` envs
     into a cold ring of trajectory buffer sets, timed with HIP events on the launch stream (same method as the headline).
     per_env_params: every env gets its own mass / load mass / tether length (rmav_set_env_param: SURVEY 8f-4, the constants
@@ -199,7 +200,7 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
     R = max(5, -(-int(1.5e9) // per_set))
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
-        env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, env_id_base=env_id_base, auto_reset=True, track_episodes=True)
         if tune:
             env.set_tuning(**tune)
         if per_env_params:
@@ -215,6 +216,8 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
         for phase, count in (("warm", W), ("timed", K)):
             if phase == "timed":
                 stream.synchronize()
+                if before_timed:   # (multi-GPU leg: the ranks' barrier)
+                    before_timed()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
                 e0.record(stream)
@@ -555,6 +558,21 @@ def main():
             exchange_check = bool(okf.item())
         if use_dist:
             totals = all_reduce_totals(totals, device="cpu" if gloo else dev)
+        if use_dist and kind == "quad3d" and args.mode == "rollout" and n != 131072 and not args.no_secondary:
+            # BASELINE configs[2]'s shape beside the weak-scaling series: 131 072 envs on EVERY rank (world = 8: exactly C3's 1 048 576),
+            # sharded by global env id, no exchange in this leg; barrier on both sides, slowest rank counts
+            try:
+                leg = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 300, 80, f"BASELINE configs[2]'s shard on each of {world} ranks",
+                                  env_id_base=rank * 131072, before_timed=dist.barrier)
+                tmax = torch.tensor([leg["ms_per_launch_wall"], leg["roofline"]["launch_ms_hip_events"]], dtype=torch.float64, device="cpu" if gloo else dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                other["c3"] = {"workload": leg["workload"], "envs_total": 131072 * world, "n_gpus": world, "launches": 300, "warmup": 80,
+                               "ms_per_launch_wall_max_over_ranks": float(tmax[0]), "launch_ms_hip_events_max_over_ranks": float(tmax[1]),
+                               "value": 131072 * world * args.chunk / (float(tmax[0]) * 1e-3), "unit": "env-steps/s",
+                               "roofline_frac_slowest_rank": leg["roofline"]["bytes_per_launch"] / (float(tmax[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "is_baseline_config_2": world == 8}
+            except Exception as e:  # pragma: no cover
+                other["c3_error"] = repr(e)
         if gathered is not None:
             gathered_finished = int((gathered[1] > 0).sum().item())
         else:   # single process: the same statistic from the local per-env buffers

@@ -190,3 +190,22 @@ def test_bench_two_ranks_one_gpu_native_exchange(stub):
     assert j2["config"]["exchange_equals_plain_all_gather"] is True
     assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_multi_gpu_line_carries_the_c3_leg(stub):
+    """Without --no-secondary a multi-rank bench line also measures BASELINE configs[2]'s shape: 131 072 envs on every rank,
+    barrier-bracketed, slowest rank counts (two ranks sharing the one GPU here, so only the plumbing is checked, not the rate)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, RMAV_BENCH_BACKEND="gloo", RMAV_BENCH_RCCL_LIB=STUB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "30",
+                        "--warmup", "6", "--prewarm-ms", "0", "--cpu-seconds", "0"], capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["envs_per_gpu"] == 65536 and j["scaling"] == "weak"
+    c3 = j["other_modes"]["c3"]
+    assert c3["envs_total"] == 2 * 131072 and c3["value"] > 0 and 0.0 < c3["roofline_frac_slowest_rank"] <= 1.0
+    assert c3["is_baseline_config_2"] is False
