@@ -38,6 +38,14 @@ roofline (dominant kernel = the timed launch; duration from HIP events on the la
   step:    SURVEY 8d's 4 (2 nS + nA + 1) + 1 = 101 B per env-step.
 cpu_baseline: the C oracle (oracle/, a port of the reference's NumPy step) timed on host cores over a bounded
 sample of the same workload.
+
+Output: the LAST stdout line is ONE compact JSON object (< 4 KB: the contract keys, ``roofline``, ``cpu_baseline``, and
+``legs`` = one short row per secondary measurement).  Everything longer - workload descriptions, byte definitions, every
+secondary leg in full, device state, the CPU thread scan, calibration - goes to ``--detail`` (default
+``gpurun_out/bench_detail.json``), named by the line's ``detail`` key; nothing else is printed to stdout, and stderr
+stays quiet unless something fails.  (Round 4's single 22 KB line could not be recovered from the driver's 8 KB tail.)
+Default ``--secondary`` = the per-step kernel at three batch sizes + the sustained stretch (~4 s); ``--secondary all``
+adds the other BASELINE configs and the policy-in-kernel rollouts (~25 s).
 """
 from __future__ import annotations
 
@@ -65,6 +73,45 @@ def _omp_set_threads(k: int):
         except Exception:
             continue
     return False
+
+
+def host_cpus():
+    """What this process may use of the box's CPU: logical CPUs present, the affinity mask, physical cores (distinct
+    (package, core) pairs of the CPUs in the mask), and the cgroup CPU quota (v2 ``cpu.max``, v1 ``cpu.cfs_quota_us`` /
+    ``cpu.cfs_period_us``; None = unlimited).  ``usable`` = min(affinity, quota rounded up) - the thread count the OpenMP
+    baseline runs at; ``usable_physical`` = the same bounded by the physical cores (SMT siblings share one FPU)."""
+    import math
+
+    present = os.cpu_count() or 1
+    aff = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(present))
+    cores = set()
+    for c in aff:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            cores.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        except Exception:
+            cores.add(("?", str(c)))
+    quota, src = None, None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        src = "/sys/fs/cgroup/cpu.max = " + q + " " + per
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            src = f"/sys/fs/cgroup/cpu/cpu.cfs_quota_us = {q}, cpu.cfs_period_us = {per}"
+            quota = None if q <= 0 else q / per
+        except Exception:
+            src = "no cgroup cpu controller file readable"
+    usable = len(aff) if quota is None else max(1, min(len(aff), int(math.ceil(quota))))
+    model = None
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"logical_present": present, "affinity": len(aff), "physical_cores_in_affinity": len(cores), "cgroup_quota_cpus": quota,
+            "cgroup_source": src, "usable": usable, "usable_physical": min(usable, len(cores)), "model": model}
 
 
 def cpu_baseline(kind: str, n: int, chunk: int, lo: float, hi: float, budget_s: float, threads: int = 1):
@@ -248,6 +295,57 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
     return out
 
 
+def step_leg(g, torch, dev, kind: str, n: int, K: int, W: int, tune=None):
+    """The per-step kernel (``rmav_step``'s ``k_step``: what baselines' one-``step()``-per-call loop issues, gym_reinmav/run.py:89 ->
+    quadrotor3d.py:81-124) as its own measurement at ``n`` envs: one launch per env-step (the loop runs inside
+    ``rmav_rollout(fused = 0)``), actions read from a ring of device buffers, state updated in place, reward + done written,
+    auto-reset + episode tracking on; HIP events on the launch stream.  At 65 536 envs a launch lasts about one launch latency;
+    262 144 and 1 048 576 envs are where the kernel, not the launch, is what is timed."""
+    A = g._abi
+    K_ = A.KIND_BY_NAME[kind]
+    nA = A.ACTION_DIM[K_]
+    algo = A.lib().rmav_algorithmic_bytes(K_)
+    p = A.default_params(K_)
+    ring_n = max(4, min(64, int(256e6) // (4 * nA * n)))
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
+        if tune:
+            env.set_tuning(**tune)
+        ring = torch.empty((ring_n, nA, n), dtype=torch.float32, device=dev).uniform_(float(p.act_lo), float(p.act_hi))
+        bufs = {"rew": torch.empty((ring_n, n), dtype=torch.float32, device=dev), "done": torch.empty((ring_n, n), dtype=torch.uint8, device=dev)}
+
+        def run(k):
+            while k > 0:
+                m = min(k, ring_n)
+                env.rollout(m, mode="buffer", actions=ring[:m], layout="soa", fused=False, want=("rew", "done"),
+                            out={"rew": bufs["rew"][:m], "done": bufs["done"][:m]})
+                k -= m
+        run(W)
+        stream.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record(stream)
+        run(K)
+        e1.record(stream)
+        stream.synchronize()
+        wall = time.perf_counter() - t0
+        ms = e0.elapsed_time(e1) / K
+        env.close()
+    del ring, bufs
+    torch.cuda.empty_cache()
+    tr, src = lookup_traffic(f"{kind}:step:1:{n}:inplace:random:soa" + ("".join(f":{k}={v}" for k, v in (tune or {}).items())))
+    return {"workload": f"one launch of k_step per env-step over {n} envs of {ENV_ID[kind]} (the loop runs inside rmav_rollout(fused = 0)): actions read "
+                        f"from a ring of {ring_n} device buffers, state updated in place, reward + done written, auto-reset + episode tracking on",
+            "launches": K, "warmup": W, "env_steps_per_launch": n, "value": n * K / wall, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * wall / K,
+            "roofline": roofline_obj(algo * n, ms, tr, src,
+                                     f"{n} envs x {algo} B (SURVEY 8d: state in/out, action in, reward + done out); the episode bookkeeping the "
+                                     "VecEnv contract adds (running return / length in/out, steps_beyond_done + reset counter in) is traffic "
+                                     "beyond this definition",
+                                     {"launch_floor_note": "an EMPTY 65 536-thread kernel chain runs 2.8-2.9 us per launch on this GPU "
+                                                           "(tools/micro/launch_floor.hip): a bound on any one-launch-per-step kernel at small batches"})}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -276,8 +374,13 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
     ap.add_argument("--tune", default="", help="comma list of key=value overrides of the launch heuristics (rmav_set_tuning), "
                                                "e.g. split=0,store_policy=2")
-    ap.add_argument("--secondary", default="in_place,step,c3_shard,c4,c4_pe,reinmav,gym1,vecenv,policy,sustained",
-                    help="comma list of the other measurements to add under other_modes (single process only)")
+    ap.add_argument("--secondary", default="step,sustained,cpu_mt",
+                    help="comma list of the other measurements (single process only): step (k_step at 65 536 / 262 144 / 1 048 576 envs), "
+                         "sustained, in_place, c3_shard, c4, c4_pe, reinmav, gym1, vecenv, policy, cpu_mt (OpenMP CPU baseline), cpu_py; "
+                         "'all' = every one of them (~25 s more)")
+    ap.add_argument("--detail", default=None,
+                    help="file that receives the full record (every leg, descriptions, device state); default gpurun_out/bench_detail.json "
+                         "(bench_detail_n<N>.json for N > 1); '-' = none")
     args = ap.parse_args()
 
     import torch
@@ -471,21 +574,14 @@ def main():
         other = {}
         single = not use_dist and not args.no_secondary
         sec = set(args.secondary.split(",")) if single else set()
+        if "all" in sec:
+            sec = {"in_place", "step", "c3_shard", "c4", "c4_pe", "reinmav", "gym1", "vecenv", "policy", "sustained", "cpu_mt", "cpu_py"}
         if "step" in sec or "in_place" in sec:
             if args.mode == "rollout" and "step" in sec:
-                w2, k2, pl2, _, _ = measure("step", 1, 4000, 200)
-                tr2, src2 = lookup_traffic(f"{kind}:step:1:{n}:inplace:{args.actions}:soa")
-                other["step"] = {"workload": "one launch of k_step per env-step (rmav_step's kernel; the loop runs inside rmav_rollout(fused = 0)): "
-                                             "actions read from a ring of 64 device buffers, state updated in place, reward + done written, "
-                                             "auto-reset + episode tracking on",
-                                 "launches": 4000, "env_steps_per_launch": n, "value": n * 4000 / w2, "unit": "env-steps/s",
-                                 "ms_per_launch_wall": 1e3 * w2 / 4000,
-                                 "roofline": roofline_obj(algo_bytes * n, k2, tr2, src2,
-                                                          f"{n} envs x {algo_bytes} B (SURVEY 8d: state in/out, action in, reward + done out); the "
-                                                          "episode bookkeeping the VecEnv contract adds (running return in/out, steps_beyond_done and "
-                                                          "reset counter in: 16 B per env-step) is traffic beyond this definition",
-                                                          {"launch_floor_note": "an EMPTY 65 536-thread kernel chain runs 2.8-2.9 us per launch on this "
-                                                                                "GPU (tools/micro/launch_floor.hip), i.e. frac <= 0.29 for any one-launch-per-step kernel"})}
+                # the per-step kernel at the headline's batch, and where it is not launch-bound (262 144 / 1 048 576 envs)
+                for n_s in sorted({n, 262144, 1048576}):
+                    key = "step" if n_s == n else f"step_{n_s}"
+                    other[key] = step_leg(g, torch, dev, kind, n_s, max(400, 4000 * 65536 // max(n_s, 65536)), 200, tune=tune)
             if args.mode == "rollout" and "in_place" in sec and not args.in_place:
                 w2, k2, pl2, _, _ = measure("rollout", args.chunk, 500, 100, in_place=True)
                 b2 = fused_bytes_per_launch(n, args.chunk, nS, nA)
@@ -609,99 +705,149 @@ def main():
                     f"BASELINE configs[2] (C3: {n_total} envs over {world} GPUs)" if (n == 131072 and kind == "quad3d" and world == 8) else
                     "BASELINE configs[2]'s per-GPU shard (131 072 envs per GPU)" if (n == 131072 and kind == "quad3d") else
                     "BASELINE configs[3] (C4)" if (world == 1 and n == 262144 and kind == "quad3d_sl") else "custom")
+        workload_long = (f"{cfg_name}: {ENV_ID[kind]}, {n} envs per GPU ({n_total} total, global env ids {rank * n}.. per rank), "
+                         f"random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
+                         + (f"one step = one fused rollout launch = {per_launch} env-steps per env, action source '{args.actions}', "
+                            f"trajectory (actions, obs, reward, done) written to HBM into "
+                            + ("ONE buffer set rewritten in place" if R == 1 else f"a ring of {R} buffer sets ({R * traj_bytes(per_launch) / 1e9:.2f} GB: cold stores)")
+                            if args.mode == "rollout"
+                            else "one step = one launch = 1 env-step per env, actions read from a device buffer, "
+                                 "obs/reward/done written"))
+        parallelism_long = (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one all-gather of "
+                            f"per-env episode stats after every {'rollout launch' if args.exchange_every == 1 else str(args.exchange_every) + ' rollout launches'}, overlapped with the next launch on a second stream: "
+                            f"{exchange_kind})") if use_dist else "single GPU"
+        roof = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_over_needed": (traffic / bytes_launch) if traffic else None,
+            "bytes_per_launch": bytes_launch, "launch_ms_hip_events": kernel_ms,
+        }
+        roof_long = dict(roof, **{
+            "traffic_source": traffic_src, "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "bytes_definition": bytes_def, "env_steps_per_launch": n * per_launch,
+            # the single-step definition applied to the fused launch (it counts 8 nS bytes of state in/out per
+            # env-step that the fused kernel keeps in registers): a speed-up-equivalent, NOT an HBM fraction
+            "algorithmic_equiv_bytes_per_env_step": algo_bytes,
+            "algorithmic_equiv_frac": algo_bytes * n * per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
         line = {
             "metric": "env-steps/sec (batched quadrotor3d-v0)" if kind == "quad3d" else f"env-steps/sec (batched {kind})",
-            "value": value,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "prewarm_ms": args.prewarm_ms,            # untimed stretch of the same launches AHEAD of the warm-up (GPU clock ramp) ...
-            "prewarm_launches": prewarm_launches[0],  # ... and the number of launches it was
-            "ms_per_step": 1e3 * wall / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if kind in ("quad2d", "quad3d") else "f64 arithmetic on f32 storage",
             "data": "synthetic",
+            "prewarm_ms": args.prewarm_ms,            # untimed stretch of the same launches AHEAD of the warm-up (GPU clock ramp) ...
+            "prewarm_launches": prewarm_launches[0],  # ... and the number of launches it was
             "config": {
-                "workload": (f"{cfg_name}: {ENV_ID[kind]}, {n} envs per GPU ({n_total} total, global env ids {rank * n}.. per rank), "
-                             f"random actions U[{lo:g},{hi:g})^{nA}, auto-reset, episode tracking; "
-                             + (f"one step = one fused rollout launch = {per_launch} env-steps per env, action source '{args.actions}', "
-                                f"trajectory (actions, obs, reward, done) written to HBM into "
-                                + ("ONE buffer set rewritten in place" if R == 1 else f"a ring of {R} buffer sets ({R * traj_bytes(per_launch) / 1e9:.2f} GB: cold stores)")
-                                if args.mode == "rollout"
-                                else "one step = one launch = 1 env-step per env, actions read from a device buffer, "
-                                     "obs/reward/done written")),
-                "kind": kind,
-                "actions": args.actions,
-                "envs_per_gpu": n,
-                "envs_total": n_total,
-                "env_steps_per_launch_per_env": per_launch,
-                "mode": args.mode,
-                "trajectory_layout": args.layout if args.mode == "rollout" else "soa",
-                "trajectory_ring": R,
-                "tune": args.tune,
-                "parallelism": (f"env-shard x{world} (contiguous global env ids, seed 0 on every rank; one all-gather of "
-                                f"per-env episode stats after every {'rollout launch' if args.exchange_every == 1 else str(args.exchange_every) + ' rollout launches'}, overlapped with the next launch on a second stream: "
-                                f"{exchange_kind})")
+                "workload": (f"{cfg_name}: {ENV_ID[kind]}, {n} envs/GPU, random actions in-kernel, auto-reset; "
+                             + (f"1 step = 1 fused {per_launch}-env-step rollout launch, trajectory written to a ring of {R} buffer sets"
+                                if args.mode == "rollout" else "1 step = 1 k_step launch (1 env-step per env)")),
+                "config_id": ("C2" if (n == 65536 and kind == "quad3d" and world == 1) else f"C2x{world}" if (n == 65536 and kind == "quad3d") else
+                              "C3" if (n == 131072 and kind == "quad3d" and world == 8) else f"C3shard x{world}" if (n == 131072 and kind == "quad3d") else
+                              "C4" if (n == 262144 and kind == "quad3d_sl" and world == 1) else "custom"),
+                "kind": kind, "actions": args.actions, "envs_per_gpu": n, "envs_total": n_total,
+                "env_steps_per_launch_per_env": per_launch, "mode": args.mode,
+                "trajectory_layout": args.layout if args.mode == "rollout" else "soa", "trajectory_ring": R, "tune": args.tune,
+                "parallelism": (f"env-shard x{world}, one all-gather of episode stats per "
+                                + ("rollout" if args.exchange_every == 1 else f"{args.exchange_every} rollouts") + ": "
+                                + ("rmav_allgather_stats_post (RCCL from librmav.so)" if (exchange_kind or "").startswith("rmav_") else
+                                   "torch.distributed all_gather_into_tensor (" + (dist.get_backend() if use_dist else "") + ")"))
                 if use_dist else "single GPU",
                 "finished_episodes": totals["episodes"],
                 "gathered_envs_with_a_finished_episode": gathered_finished,
                 "exchange_equals_plain_all_gather": exchange_check,
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_source": traffic_src,
-                "traffic_frac": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "traffic_over_needed": (traffic / bytes_launch) if traffic else None,
-                "bytes_per_launch": bytes_launch,
-                "bytes_definition": bytes_def,
-                "launch_ms_hip_events": kernel_ms,
-                "env_steps_per_launch": n * per_launch,
-                # the single-step definition applied to the fused launch (it counts 8 nS bytes of state in/out per
-                # env-step that the fused kernel keeps in registers): a speed-up-equivalent, NOT an HBM fraction
-                "algorithmic_equiv_bytes_per_env_step": algo_bytes,
-                "algorithmic_equiv_frac": algo_bytes * n * per_launch / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            },
-            "device_state": device_state,
+            "roofline": roof,
         }
+        detail = dict(line)
+        detail["config"] = dict(line["config"], workload=workload_long, parallelism=parallelism_long)
+        detail["roofline"] = roof_long
+        detail["device_state"] = device_state
+        detail["host_cpus"] = hc = host_cpus()
         if other:
-            line["other_modes"] = other
+            detail["other_modes"] = other
         calib = os.path.join(ROOT, "profiles", "cpu_calibration.json")
         if os.path.exists(calib):   # build-CPU / reference ratio per kind, measured in the authoring container (oracle/calibrate.py)
-            line["calibration"] = json.load(open(calib))
+            detail["calibration"] = json.load(open(calib))
         if world == 1 and not use_dist and args.cpu_seconds > 0 and kind != "reinmav":
-            line["cpu_baseline"] = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
-            ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-            if ncpu > 1:
-                # the same port with OpenMP over envs.  Containers often expose more logical CPUs than their
-                # quota lets them use, so a few thread counts are tried briefly and the best one is reported
-                # (cores = the threads actually used for that number).
-                best = None
-                for k in sorted({c for c in (4, 16, 64, ncpu) if c <= ncpu}):
-                    r = cpu_baseline(kind, n, args.chunk, lo, hi, min(1.5, args.cpu_seconds), threads=k)
-                    if best is None or r["value"] > best["value"]:
-                        best = r
-                line["cpu_baseline_multithread"] = best
-            # interpreter-bound stand-in for the reference's own Python (which cannot travel to this box):
-            # a per-env NumPy restatement in the reference's style (oracle/numpy_ref.py), ~2 s sample
-            try:
-                import numpy_ref
+            cb = cpu_baseline(kind, n, args.chunk, lo, hi, args.cpu_seconds, threads=1)
+            detail["cpu_baseline"] = cb
+            line["cpu_baseline"] = dict(cb, sample=f"{kind} C oracle (fp64 scalar port of the reference step), {n} envs, random actions + auto-reset, "
+                                                   f"{args.cpu_seconds:g} s, 1 thread; host has {hc['usable']} usable CPUs")
+            if "cpu_mt" in sec and hc["usable"] > 1:
+                # the same port with OpenMP over envs (static schedule) at the thread count this process may actually use:
+                # min(affinity mask, cgroup quota), and at the physical-core count when SMT doubles it; >= 3 s each
+                scan = {}
+                for k in sorted({hc["usable"], hc["usable_physical"]}):
+                    scan[k] = cpu_baseline(kind, n, args.chunk, lo, hi, max(3.0, min(5.0, args.cpu_seconds)), threads=k)
+                best = max(scan.values(), key=lambda r: r["value"])
+                best = dict(best, cores_available=hc["usable"], physical_cores=hc["physical_cores_in_affinity"],
+                            cgroup_quota_cpus=hc["cgroup_quota_cpus"], speedup_over_1_thread=best["value"] / cb["value"],
+                            parallel_efficiency=best["value"] / cb["value"] / best["cores"],
+                            scan={str(k): r["value"] for k, r in scan.items()})
+                detail["cpu_baseline_multithread"] = best
+                line["cpu_mt"] = {"value": best["value"], "cores": best["cores"], "cores_available": hc["usable"],
+                                  "efficiency": round(best["parallel_efficiency"], 3)}
+            if "cpu_py" in sec:
+                # interpreter-bound stand-in for the reference's own Python (which cannot travel to this box):
+                # a per-env NumPy restatement in the reference's style (oracle/numpy_ref.py), ~2 s sample
+                try:
+                    import numpy_ref
 
-                v, k, el = numpy_ref.time_steps(min(2.0, args.cpu_seconds))
-                line["cpu_baseline_python"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
-                                               "sample": f"per-env NumPy restatement of Quadrotor3D.step, {k} env-steps, "
-                                                         f"{el:.1f} s, 1 process (the reference itself ran at 16.1 k "
-                                                         "env-steps/s in the authoring container, BASELINE.md section 2)"}
-            except Exception as e:  # pragma: no cover
-                line["cpu_baseline_python"] = {"error": repr(e)}
-        print(json.dumps(line), flush=True)
+                    v, k, el = numpy_ref.time_steps(min(2.0, args.cpu_seconds))
+                    detail["cpu_baseline_python"] = {"value": v, "unit": "env-steps/s", "cores": 1, "kind": "port",
+                                                     "sample": f"per-env NumPy restatement of Quadrotor3D.step, {k} env-steps, "
+                                                               f"{el:.1f} s, 1 process (the reference itself ran at 16.1 k "
+                                                               "env-steps/s in the authoring container, BASELINE.md section 2)"}
+                except Exception as e:  # pragma: no cover
+                    detail["cpu_baseline_python"] = {"error": repr(e)}
+        # one short row per secondary leg (the full objects are in the detail file)
+        legs = {}
+        for k, v in other.items():
+            if not isinstance(v, dict):
+                legs[k] = str(v)[:120]
+                continue
+            row = {}
+            if "value" in v:
+                row["value"] = float(f"{v['value']:.4g}")
+            r_ = v.get("roofline")
+            if isinstance(r_, dict) and "frac" in r_:
+                row["frac"] = round(r_["frac"], 4)
+                row["us"] = round(1e3 * r_["launch_ms_hip_events"], 3)
+                if r_.get("traffic_over_needed"):
+                    row["traffic_over_needed"] = round(r_["traffic_over_needed"], 3)
+            elif "roofline_frac" in v:
+                row["frac"] = round(v["roofline_frac"], 4)
+                row["us"] = round(1e3 * v.get("ms_per_launch_hip_events", 0.0), 3)
+            elif "roofline_frac_slowest_rank" in v:
+                row["frac"] = round(v["roofline_frac_slowest_rank"], 4)
+                row["envs_total"] = v.get("envs_total")
+            if k == "policy_rollout":
+                row = {a: {"value": float(f"{x['kernel_env_steps_per_s']:.4g}"), "bound": x["bound"], "frac": round(x["bound_frac"], 3)}
+                       for a, x in v.items() if isinstance(x, dict) and "bound" in x}
+            if k == "gym1":
+                row = {"us_control_plus_step": round(v["us_per_iteration_control_plus_step"], 2), "reference_us_per_step": v["reference_us_per_step"]}
+            if k == "vecenv":
+                row = {kk: round(vv["us_per_step"], 2) for kk, vv in v.items() if isinstance(vv, dict)}
+            legs[k] = row
+        if legs:
+            line["legs"] = legs
+        dpath = args.detail
+        if dpath is None:
+            dpath = os.path.join(ROOT, "gpurun_out", "bench_detail.json" if world == 1 else f"bench_detail_n{world}.json")
+        if dpath != "-":
+            try:
+                os.makedirs(os.path.dirname(os.path.abspath(dpath)), exist_ok=True)
+                with open(dpath, "w") as f:
+                    json.dump(detail, f, indent=1)
+                line["detail"] = os.path.relpath(dpath, ROOT) if os.path.abspath(dpath).startswith(ROOT) else dpath
+            except Exception as e:  # pragma: no cover - the line matters more than the file
+                line["detail"] = "not written: " + repr(e)[:80]
+        text = json.dumps(line, separators=(",", ":"))
+        if len(text) > 4000:   # never again a line the driver cannot recover: drop the optional rows first
+            for k in ("legs", "cpu_mt"):
+                line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+        sys.stdout.flush()
+        print(text, flush=True)
     if native_abandoned:   # a thread of this process is still inside RCCL: do not wait for it in any destructor
         sys.stdout.flush()
         sys.stderr.flush()

@@ -330,7 +330,7 @@ RolloutArgs base_args(rmav_handle h) {
     a.sbd = h->sbd;
     a.reset_cnt = h->reset_cnt;
     a.ep_ret = h->ep_ret;
-    a.ep_len = h->ep_len;
+    a.ep_start = h->ep_start;
     a.last_ret = h->last_ret;
     a.last_len = h->last_len;
     a.totals = h->totals;
@@ -350,7 +350,7 @@ int launch_reset(rmav_handle h, float *obs_dev, int layout) {
     const uint32_t fl = (h->flags & F_TRACK) | (layout == RMAV_AOS ? F_AOS : 0u);
 #define RMAV_RESET_CASE(KIND)                                                                      \
     hipLaunchKernelGGL((k_reset<KIND>), grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,      \
-                       h->n, h->reset_cnt, h->ep_ret, h->ep_len, obs_dev, h->seed, h->env_base, fl)
+                       h->n, h->reset_cnt, h->ep_ret, h->ep_start, (uint32_t)h->t, obs_dev, h->seed, h->env_base, fl)
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_RESET_CASE(QUAD2D); break;
     case RMAV_QUAD2D_SL: RMAV_RESET_CASE(QUAD2D_SL); break;
@@ -590,7 +590,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         if (tr) {
             h->ep_ret = (float *)(b + o_er);
             h->last_ret = (float *)(b + o_lr);
-            h->ep_len = (int32_t *)(b + o_el);
+            h->ep_start = (uint32_t *)(b + o_el);
             h->last_len = (int32_t *)(b + o_ll);
         }
     }
@@ -600,7 +600,7 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
     if (e == hipSuccess && (flags & RMAV_F_TRACK_EPISODES)) {
         e = hipMemsetAsync(h->ep_ret, 0, n * sizeof(float), h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->last_ret, 0, n * sizeof(float), h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(h->ep_len, 0, n * sizeof(int32_t), h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(h->ep_start, 0, n * sizeof(uint32_t), h->stream);   // the clock starts at 0
         if (e == hipSuccess) e = hipMemsetAsync(h->last_len, 0, n * sizeof(int32_t), h->stream);
     }
     if (e != hipSuccess) {
@@ -642,10 +642,22 @@ int rmav_destroy(rmav_handle h) {
     return RMAV_OK;
 }
 
+// t is also the episode clock (rmav_kernels.hpp: ep_clock0): when a caller moves it, every env's episode start moves along,
+// so running episode lengths carry over the jump
+static int move_step_counter(rmav_handle h, uint64_t t) {
+    const uint32_t delta = (uint32_t)t - (uint32_t)h->t;
+    if (delta != 0u && (h->flags & RMAV_F_TRACK_EPISODES)) {
+        hipLaunchKernelGGL(k_shift_u32, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->ep_start, delta, (int64_t)h->n);
+        HIP_TRY(hipGetLastError());
+    }
+    h->t = t;
+    return RMAV_OK;
+}
+
 int rmav_seed(rmav_handle h, uint64_t seed) {
     CHECK_HANDLE(h);
     h->seed = seed;
-    h->t = 0;
+    if (int rc = move_step_counter(h, 0)) return rc;
     HIP_TRY(hipMemsetAsync(h->reset_cnt, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
     return RMAV_OK;
 }
@@ -1110,9 +1122,8 @@ int rmav_get_step_count(rmav_handle h, uint64_t *out) {
     return RMAV_OK;
 }
 int rmav_set_step_count(rmav_handle h, uint64_t t) {
-    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_handle");
-    h->t = t;
-    return RMAV_OK;
+    CHECK_HANDLE(h);
+    return move_step_counter(h, t);
 }
 
 int rmav_episode_totals(rmav_handle h, rmav_ep_totals *out, int clear) {
@@ -1153,8 +1164,18 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
     if (last_return) HIP_TRY(hipMemcpyAsync(last_return, h->last_ret, n * sizeof(float), kind, h->stream));
     if (last_length) HIP_TRY(hipMemcpyAsync(last_length, h->last_len, n * sizeof(int32_t), kind, h->stream));
     if (cur_return) HIP_TRY(hipMemcpyAsync(cur_return, h->ep_ret, n * sizeof(float), kind, h->stream));
-    if (cur_length) HIP_TRY(hipMemcpyAsync(cur_length, h->ep_len, n * sizeof(int32_t), kind, h->stream));
-    if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint32_t clock = (uint32_t)h->t;   // running length = episode clock - the episode's start
+    if (cur_length && mem == RMAV_DEVICE) {
+        hipLaunchKernelGGL(k_cur_length, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, cur_length, h->ep_start, clock, (int64_t)n);
+        HIP_TRY(hipGetLastError());
+    } else if (cur_length) {
+        HIP_TRY(hipMemcpyAsync(cur_length, h->ep_start, n * sizeof(int32_t), kind, h->stream));
+    }
+    if (mem == RMAV_HOST) {
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (cur_length)
+            for (size_t i = 0; i < n; ++i) cur_length[i] = (int32_t)(clock - (uint32_t)cur_length[i]);
+    }
     return RMAV_OK;
 }
 

@@ -178,6 +178,17 @@ __global__ __launch_bounds__(256) void k_pack_policy(const PackSrc src, const in
     }
 }
 
+// running episode lengths for rmav_episode_buffers: clock - ep_start
+__global__ __launch_bounds__(256) void k_cur_length(int32_t *out, const uint32_t *ep_start, uint32_t clock, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)(clock - ep_start[i]);
+}
+
+__global__ __launch_bounds__(256) void k_shift_u32(uint32_t *x, uint32_t delta, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += delta;
+}
+
 // ---- episode statistics exchange (the path's one collective) ------------------------------------------------
 // send = [2][cmax] int32: returns (bit pattern) then lengths of this rank's `count` envs, zero padded to cmax
 __global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ last_ret, const int32_t *__restrict__ last_len,

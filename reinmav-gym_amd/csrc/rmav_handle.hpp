@@ -49,7 +49,8 @@ struct rmav_env_s {
     int32_t *sbd;
     uint32_t *reset_cnt;
     float *ep_ret, *last_ret;
-    int32_t *ep_len, *last_len;
+    uint32_t *ep_start;  // (uint32_t)t at the start of each env's running episode (rmav_kernels.hpp: ep_clock0)
+    int32_t *last_len;
     rmav::Totals *totals;
     double *env_time;  // RMAV_REINMAV only
     void *arena;       // ONE allocation behind all of the arrays above (see rmav_create)

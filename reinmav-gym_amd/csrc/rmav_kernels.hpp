@@ -135,7 +135,7 @@ struct RolloutArgs {
     int32_t *sbd;
     uint32_t *reset_cnt;
     float *ep_ret;
-    int32_t *ep_len;
+    uint32_t *ep_start;     // value of the handle's episode clock when the env's running episode began: length = clock - ep_start
     float *last_ret;
     int32_t *last_len;
     Totals *totals;
@@ -173,6 +173,14 @@ struct RolloutArgs {
     uint32_t *done_flag;
     uint32_t done_seq;
 };
+
+// Episode lengths are not stored: every env keeps the value the episode clock had when its running episode began (ep_start).
+// The clock is the low 32 bits of the handle's step counter t (rmav_seed / rmav_set_step_count, which move t, shift ep_start
+// by the same amount) - a value every stepping kernel has in scalar registers anyway, so the scheme costs no register.  A fused kernel turns that into a
+// running length once (clock0 - ep_start), counts in registers as before, and writes clock0 + n_steps - length back; the
+// single-step kernel touches ep_start only in lanes whose episode ends - no per-step read-modify-write of a length array
+// (8 B of 24 B of bookkeeping traffic per env-step; round 5).  32-bit wrap-around is harmless: only differences are used.
+__device__ __forceinline__ uint32_t ep_clock0(const RolloutArgs &a) { return (uint32_t)a.t0; }
 
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
 #pragma unroll
@@ -753,7 +761,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         int32_t el = 0;
         if (track) {
             er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-            el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+            el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
         }
         // steps_beyond_done and the reset counter ride in registers for the whole launch: loading them
         // on demand (only lanes that terminate need them) would put one or two dependent HBM round
@@ -1175,7 +1183,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         }
         if (track) {
             buf_st(make_rsrc(a.ep_ret), off, 0, er);
-            buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+            buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
         }
         if constexpr (K == REINMAV) a.env_time[li] = tenv;
         buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
@@ -1336,16 +1344,15 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * tcol);
     }
     float er = 0.0f;
-    int32_t el = 0;
-    if (track) {
-        er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-        el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
-    }
+    if (track) er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+    // needed only by lanes whose env terminates in this step: steps_beyond_done (the terminal reward), the reset counter
+    // (the Philox counter of the fresh state) and the episode's start (its length)
     int32_t sb = -1;
-    uint32_t rc = 0;
+    uint32_t rc = 0, es = 0;
     if constexpr (!LAZY) {
         sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
         rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+        if (track) es = (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0);
     }
     typename Env<K>::P pl = p_shared;
     ParamsT<double> pcl = pc_shared;
@@ -1364,6 +1371,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         if (done) {   // only the finishing lanes fetch (one 32-byte sector each instead of the wavefront's 256 bytes)
             sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
             rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+            if (track) es = (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0);
         }
     }
     // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
@@ -1381,18 +1389,18 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, AUX);
         if (track) {
             er += r;
-            el += 1;
             if (done) {
+                const uint32_t clk = ep_clock0(a) + 1u;       // the episode clock after this step
+                const int32_t el = (int32_t)(clk - es);       // steps of the episode that ends here
                 buf_st(make_rsrc(a.last_ret), off, 0, er);
                 buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)clk);   // the next episode starts now
                 fin = true;
                 fin_ret = er;
                 fin_len = el;
                 er = 0.0f;
-                el = 0;
             }
             buf_st_aux<AUX>(make_rsrc(a.ep_ret), off, 0, er);
-            buf_st_aux<AUX>(make_rsrc(a.ep_len), off, 0, __builtin_bit_cast(float, el));
         }
         if (done) {
             buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
@@ -1462,7 +1470,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
 // reset() of every env
 template <int K>
 __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint32_t *reset_cnt,
-                                                  float *ep_ret, int32_t *ep_len, float *obs_out,
+                                                  float *ep_ret, uint32_t *ep_start, uint32_t ep_clock, float *obs_out,
                                                   uint64_t seed, uint64_t env_base, uint32_t flags) {
     constexpr int NS = Dims<K>::NS;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1480,7 +1488,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint3
     reset_cnt[i] = rc + 1;
     if (flags & F_TRACK) {
         ep_ret[i] = 0.0f;
-        ep_len[i] = 0;
+        ep_start[i] = ep_clock;   // running length 0
     }
     if (obs_out) {
         if (flags & F_AOS) {

@@ -325,7 +325,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     int32_t el = 0;
     if (track) {
         er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-        el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+        el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
     }
     int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
     uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
     if (track) {
         buf_st(make_rsrc(a.ep_ret), off, 0, er);
-        buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+        buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
     }
     if constexpr (K == REINMAV) a.env_time[li] = tenv;
     buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
     int32_t el = 0;
     if (track) {
         er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-        el = buf_ld_i32(make_rsrc(a.ep_len), off, 0);
+        el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
     }
     int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
     uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
@@ -782,7 +782,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
     for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
     if (track) {
         buf_st(make_rsrc(a.ep_ret), off, 0, er);
-        buf_st_i32(make_rsrc(a.ep_len), off, 0, el);
+        buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
     }
     if constexpr (K == REINMAV) a.env_time[li] = tenv;
     buf_st_i32(make_rsrc(a.sbd), off, 0, sb);

@@ -41,21 +41,15 @@ class NativeQuadrotorEnv(_EnvBase):
         nS, nA = A.STATE_DIM[kind], A.ACTION_DIM[kind]
         lo, hi, dt = self._action_box
         self.action_space = Box(low=lo, high=hi, shape=(nA,), dtype=dt)
-        self.observation_space = Box(low=-10.0, high=10.0, shape=(nS,), dtype=dt)
+        self.observation_space = Box(low=-10.0, high=10.0, shape=(nS,), dtype=np.float64)   # quadrotor3d.py:71 dtype=np.float
         self.viewer = None
         self._seed_value = self._fresh_seed() if seed is None else int(seed)
         # gym.Env semantics: no auto-reset, no Monitor; the constructor seeds then resets
         # (quadrotor3d.py:73-74), which rmav_create does as well.
         self._batch = BatchedQuadrotor(kind, 1, device=device, seed=self._seed_value, auto_reset=False,
                                        track_episodes=False, reading_2d=self._reading_2d)
-        p = self._batch.params
-        self.mass, self.dt = p.mass, p.dt
-        self.g = np.array([0.0, -p.g]) if nS in (5, 9) else np.array([0.0, 0.0, -p.g])
-        dim = 2 if nS in (5, 9) else 3
-        self.ref_pos = np.array(list(p.ref_pos)[:dim])
-        self.ref_vel = np.array(list(p.ref_vel)[:dim])
-        if nS in (9, 16):
-            self.load_mass, self.tether_length = p.load_mass, p.tether_length
+        self._dim = 2 if nS in (5, 9) else 3
+        self._has_load = nS in (9, 16)
         # Lean per-call path: preallocated host arrays and cached ctypes pointers, so a step() is one ABI call
         # (= one kernel launch + one stream synchronise through the handle's pinned block) plus a few small
         # NumPy conversions.  The launch also evaluates control() on the new state (rmav_step_control), so the
@@ -133,10 +127,104 @@ class NativeQuadrotorEnv(_EnvBase):
         self._ctrl_valid = False
         self._batch.set_sbd(np.array([-1 if v is None else int(v)], dtype=np.int32))
 
-    @property
-    def pos_threshold(self):
-        return self._batch.params.pos_limit
+    # The reference reads these on EVERY call (quadrotor3d.py:86 `self.mass`, :96-102 `self.dt`, `self.g`, :148 `self.ref_pos`,
+    # :162 `self.ref_vel`, :107-110 the thresholds; quadrotor3d_slungload.py:101-128 `self.load_mass`, `self.tether_length`), so
+    # assigning one of them - or writing an element of the array-valued ones - changes the next step() / control().  Here
+    # they are views of the handle's rmav_params: a getter reads it, a setter writes it back through rmav_set_params (the
+    # derived constants are recomputed at the next launch) and drops the cached control() action.
+    def _set_param(self, **kv):
+        p = self._batch.params
+        for k, v in kv.items():
+            if k in ("ref_pos", "ref_vel"):
+                v = np.asarray(v, dtype=np.float64).reshape(-1)
+                if v.shape != (self._dim,):
+                    raise ValueError(f"{k} must have {self._dim} components")
+                arr = getattr(p, k)
+                for i in range(self._dim):
+                    arr[i] = float(v[i])
+            else:
+                setattr(p, k, float(v))
+        self._batch.params = p          # rmav_set_params validates (raises RmavError on e.g. mass <= 0)
+        self._ctrl_valid = False
+
+    def _vec(self, values, setter):
+        a = _WriteThrough(np.asarray(values, dtype=np.float64))
+        a._on_write = setter
+        return a
+
+    mass = property(lambda self: self._batch.params.mass, lambda self, v: self._set_param(mass=v))
+    dt = property(lambda self: self._batch.params.dt, lambda self, v: self._set_param(dt=v))
+    pos_threshold = property(lambda self: self._batch.params.pos_limit, lambda self, v: self._set_param(pos_limit=v))
+    vel_threshold = property(lambda self: self._batch.params.vel_limit, lambda self, v: self._set_param(vel_limit=v))
+
+    def _load_attr(name):  # noqa: N805 - class-body helper: slung-load classes only, AttributeError elsewhere like the reference
+        def get(self):
+            if not self._has_load:
+                raise AttributeError(f"{type(self).__name__!r} object has no attribute {name!r}")
+            return getattr(self._batch.params, name)
+
+        def set_(self, v):
+            if not self._has_load:      # the reference would just grow an unused attribute
+                object.__setattr__(self, "_unused_" + name, v)
+                return
+            self._set_param(**{name: v})
+        return property(get, set_)
+
+    load_mass = _load_attr("load_mass")
+    tether_length = _load_attr("tether_length")
+    del _load_attr
 
     @property
-    def vel_threshold(self):
-        return self._batch.params.vel_limit
+    def g(self):
+        """Gravity vector (0, [0,] -g) like quadrotor3d.py:47; only its vertical component can be non-zero here."""
+        v = [0.0] * (self._dim - 1) + [-self._batch.params.g]
+        return self._vec(v, self._set_g)
+
+    @g.setter
+    def g(self, v):
+        self._set_g(v)
+
+    def _set_g(self, v):
+        v = np.asarray(v, dtype=np.float64).reshape(-1)
+        if v.shape != (self._dim,) or np.any(v[:-1] != 0.0):
+            raise ValueError("g must be (0, " + ("0, " if self._dim == 3 else "") + "-g): the device path models vertical gravity only")
+        self._set_param(g=-float(v[-1]))
+
+    @property
+    def ref_pos(self):
+        return self._vec(list(self._batch.params.ref_pos)[:self._dim], lambda v: self._set_param(ref_pos=v))
+
+    @ref_pos.setter
+    def ref_pos(self, v):
+        self._set_param(ref_pos=v)
+
+    @property
+    def ref_vel(self):
+        return self._vec(list(self._batch.params.ref_vel)[:self._dim], lambda v: self._set_param(ref_vel=v))
+
+    @ref_vel.setter
+    def ref_vel(self, v):
+        self._set_param(ref_vel=v)
+
+
+class _WriteThrough(np.ndarray):
+    """The array a vector-valued attribute getter hands out: ``env.ref_pos[2] = 1.0`` must move the set-point as it does in the
+    reference (whose ``self.ref_pos`` IS the array control() reads), so element writes are pushed back to the handle.
+    Arithmetic on it yields plain ndarrays."""
+
+    _on_write = None
+
+    def __new__(cls, values):
+        return np.asarray(values, dtype=np.float64).view(cls)
+
+    def __array_finalize__(self, obj):
+        self._on_write = None           # views / results of arithmetic do not write through
+
+    def __setitem__(self, key, value):
+        np.ndarray.__setitem__(self, key, value)
+        if self._on_write is not None:
+            self._on_write(np.asarray(self))
+
+    def __array_wrap__(self, out, context=None, return_scalar=False):
+        out = np.asarray(out)
+        return out[()] if return_scalar else out

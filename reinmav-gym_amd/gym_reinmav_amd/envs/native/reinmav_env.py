@@ -47,6 +47,18 @@ class ReinmavEnv(_EnvBase):
         """(F, Mx, My, Mz) the built-in controller commands at the current (state, t)  (reinmav_env.py:306-337)."""
         return self._batch.control()[0].astype(np.float64)
 
+    def trj_gen(self, t):
+        """The min-jerk reference the built-in controller tracks (reinmav_env.py:128-136), host side, for callers that plot or
+        inspect it: a quintic in s = clip(t, 0, 4 s) / 4 s and its first two time derivatives, the same profile on x, y, z (and
+        yaw) -> [x, y, z, vx, vy, vz, ax, ay, az, yaw, yaw rate].  The device path evaluates the same polynomial every sub-step
+        (csrc/rmav_math.hpp, Env<REINMAV>)."""
+        T = 4.0
+        s = min(max(float(t), 0.0), T) / T
+        pos = s ** 3 * (10.0 + s * (-15.0 + 6.0 * s))
+        vel = s ** 2 * (30.0 + s * (-60.0 + 30.0 * s)) / T
+        acc = s * (60.0 + s * (-180.0 + 120.0 * s)) / T ** 2
+        return [pos] * 3 + [vel] * 3 + [acc] * 3 + [pos, vel]
+
     def reset(self):
         return self.state   # reinmav_env.py:348-351: returns the current state, changes nothing
 

@@ -4,8 +4,8 @@ What the reference reaches through ``baselines.common.cmd_util.make_vec_env`` in
 ``gym_reinmav/run.py:89`` - ``SubprocVecEnv`` / ``DummyVecEnv`` of ``Monitor``-wrapped envs - is one
 object here: ``reset() -> obs[N,nS]``, ``step_async(actions[N,nA])``, ``step_wait() -> (obs, rews,
 dones, infos)`` with auto-reset on done (the returned obs of a finished env is its post-reset obs,
-as in ``DummyVecEnv.step_wait``) and ``info['episode'] = {'r', 'l'}`` for finished envs (what
-``Monitor`` adds).  Observations stay on the GPU as torch tensors unless ``numpy_io=True``.
+as in ``DummyVecEnv.step_wait``) and ``info['episode'] = {'r', 'l', 't'}`` for finished envs (what
+``Monitor`` adds: return, length, seconds since the env was created).  Observations stay on the GPU as torch tensors unless ``numpy_io=True``.
 
 The per-step loop of ``gym_reinmav/run.py:190-211`` / ppo2's ``Runner`` calls ``step`` once per env-step, and
 at 65 536 envs the kernel behind it runs ~4.5 us - so the wrapper must cost less than that or it, not the GPU,
@@ -17,6 +17,7 @@ in blocks, an action tensor that already is float32 / contiguous / on the env's 
 from __future__ import annotations
 
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -37,16 +38,21 @@ _BLOCK = 16   # steps of fresh output tensors allocated at a time (one allocatio
 
 class LazyInfos:
     """``infos`` of one ``step_wait()`` of a big batch: behaves like baselines' ``list[dict]`` - ``len``, indexing, iteration,
-    ``info.get('episode')`` with ``{'r', 'l'}`` for the envs that finished an episode in this step (what ``Monitor`` adds,
+    ``info.get('episode')`` with ``{'r', 'l', 't'}`` for the envs that finished an episode in this step (what ``Monitor`` adds,
     what ppo2's ``Runner`` collects into ``epinfos``) - but builds nothing until somebody looks: the done mask and the two
     statistics arrays come off the GPU on first use, and only the finished envs (~1 % per step) get a non-empty dict.
-    65 536 fresh dicts per step would cost ~3 ms of host time against a 5 us step."""
+    65 536 fresh dicts per step would cost ~3 ms of host time against a 5 us step.
 
-    __slots__ = ("_n", "_done", "_env", "_eps", "_seq")
-    _EMPTY: dict = {}
+    One object per step (never recycled): an object kept past the next step raises when first read - the per-env statistics it
+    would report have moved on - instead of silently answering for a later step.  An env that did not finish gets a fresh
+    empty dict per access (never a shared one: a caller that writes ``infos[i]['x'] = ...`` must not touch other envs or later
+    steps); a caller that wants such writes to persist asks for ``dict_infos=True``."""
+
+    __slots__ = ("_n", "_done", "_env", "_eps", "_seq", "_t")
 
     def __init__(self, n, done, env, seq):
         self._n, self._done, self._env, self._eps, self._seq = n, done, env, None, seq
+        self._t = round(time.time() - env._tstart, 6)
 
     def _episodes(self):
         if self._eps is None:
@@ -59,7 +65,7 @@ class LazyInfos:
             if len(idx):
                 buf = self._env.env.episode_buffers()
                 for i in idx:
-                    eps[int(i)] = {"episode": {"r": float(buf["last_return"][i]), "l": int(buf["last_length"][i])}}
+                    eps[int(i)] = {"episode": {"r": float(buf["last_return"][i]), "l": int(buf["last_length"][i]), "t": self._t}}
             self._eps = eps
         return self._eps
 
@@ -73,11 +79,12 @@ class LazyInfos:
             i += self._n
         if not 0 <= i < self._n:
             raise IndexError(i)
-        return self._episodes().get(i, self._EMPTY)
+        e = self._episodes().get(i)
+        return {} if e is None else e
 
     def __iter__(self):
         eps = self._episodes()
-        return (eps.get(i, self._EMPTY) for i in range(self._n))
+        return (eps.get(i) or {} for i in range(self._n))
 
     def finished(self):
         """{env index: {'episode': {'r', 'l'}}} of the envs that finished in this step (the non-empty infos)."""
@@ -100,7 +107,7 @@ class QuadrotorVecEnv:
         self.observation_space = Box(low=-10.0, high=10.0, shape=(self.env.nS,), dtype=np.float32)
         self._pending = None
         self._info_seq = 0   # step counter of the lazily materialised infos
-        self._lazy = (LazyInfos(self.num_envs, None, self, -1), LazyInfos(self.num_envs, None, self, -1))
+        self._tstart = time.time()   # Monitor's tstart: info['episode']['t'] = seconds since the env was made
         # reuse_buffers=True: step_wait() hands out the env's own output buffers (two sets, alternating), valid
         # until the step after next.  The default returns tensors no later step overwrites, like baselines'
         # DummyVecEnv (whose Runner keeps the returned reward arrays): slices of blocks of _BLOCK steps.
@@ -181,18 +188,17 @@ class QuadrotorVecEnv:
 
     def _infos(self, done_b):
         if not self.dict_infos:
-            # two objects, alternating (an allocation per step would cost ~0.3 us of a 5 us step): the one handed out two steps
-            # ago is stale by then anyway and says so when read (its sequence number no longer matches)
+            # a fresh object per step (~0.3 us): one that is read after a later step sees that its sequence number no longer
+            # matches and raises (recycled objects, round 4, passed that check two steps later and answered for the wrong step)
             self._info_seq = seq = self._info_seq + 1
-            li = self._lazy[seq & 1]
-            li._done, li._eps, li._seq = done_b, None, seq
-            return li
+            return LazyInfos(self.num_envs, done_b, self, seq)
         infos = [{} for _ in range(self.num_envs)]
         idx = np.nonzero(done_b if self.numpy_io else done_b.cpu().numpy())[0]
         if len(idx):
             buf = self.env.episode_buffers()
+            t = round(time.time() - self._tstart, 6)
             for i in idx:
-                infos[int(i)]["episode"] = {"r": float(buf["last_return"][i]), "l": int(buf["last_length"][i])}
+                infos[int(i)]["episode"] = {"r": float(buf["last_return"][i]), "l": int(buf["last_length"][i]), "t": t}
         return infos
 
     def close(self):

@@ -97,6 +97,96 @@ def test_gym_env_attributes(G):
     e2.close()
 
 
+def test_gym_env_public_attributes_write_through(G):
+    """The reference reads self.mass / dt / g / ref_pos / ref_vel / thresholds (and load_mass / tether_length) on every call
+    (quadrotor3d.py:86,96-102,148,162; quadrotor3d_slungload.py:101-128), so assigning them - or an element of the array-valued
+    ones - changes the next control() / step().  Same here: the attributes are views of the handle's rmav_params."""
+    from util import CTRL_TOL, TOL, scaled_err
+
+    def assert_close(x, ref, tol):
+        assert scaled_err(x, ref).max() <= tol, scaled_err(x, ref).max()
+
+    def ctrl_close(a, ref):
+        assert scaled_err(a, ref).max() <= CTRL_TOL, scaled_err(a, ref).max()
+
+    STATE_TOL = TOL
+
+    env = G.make("quadrotor3d-v0", seed=3)
+    s0 = env.reset()
+    a_default = env.control()
+    ctrl_close(a_default, O.control("quad3d", s0))
+    # whole-array assignment, then element assignment
+    env.ref_pos = (1.0, 0.0, 1.0)
+    env.mass = 1.3
+    p = O.default_params("quad3d")
+    p.mass = 1.3
+    p.ref_pos[0], p.ref_pos[1], p.ref_pos[2] = 1.0, 0.0, 1.0
+    assert list(env.ref_pos) == [1.0, 0.0, 1.0] and env.mass == 1.3
+    a = env.control()
+    exp = O.control("quad3d", s0, p)
+    assert np.abs(a - a_default).max() > 1e-3           # the set-point moved the command
+    ctrl_close(a, exp)
+    obs, r, d, _ = env.step(a)                          # the step uses the new mass
+    s1, r1, d1, _ = O.step("quad3d", s0, a.astype(np.float32).astype(np.float64), None, p)
+    assert_close(obs, s1, STATE_TOL)
+    assert abs(r - r1) <= 1e-6 * max(1.0, abs(r1)) and d == d1
+    # after step() the class holds a cached control() action: an attribute write must drop it
+    cached = env.control()
+    env.ref_pos[2] = 2.5                                # element write on the handed-out array (the reference's self.ref_pos IS the array)
+    p.ref_pos[2] = 2.5
+    assert env.ref_pos[2] == 2.5
+    a2 = env.control()
+    exp2 = O.control("quad3d", obs, p)
+    assert np.abs(a2 - cached).max() > 1e-3
+    ctrl_close(a2, exp2)
+    env.ref_vel = [0.1, 0.0, -0.1]
+    env.dt = 0.02
+    env.g = np.array([0.0, 0.0, -3.7])
+    p.ref_vel[0], p.ref_vel[2], p.dt, p.g = 0.1, -0.1, 0.02, 3.7
+    assert list(env.g) == [0.0, 0.0, -3.7] and env.dt == 0.02
+    a3 = env.control()
+    ctrl_close(a3, O.control("quad3d", obs, p))
+    o2, r2, d2, _ = env.step(a3)
+    s2, rr2, dd2, _ = O.step("quad3d", obs, a3.astype(np.float32).astype(np.float64), None, p)
+    assert_close(o2, s2, STATE_TOL)
+    env.pos_threshold = 0.01                            # every state is now out of bounds: the next step terminates
+    assert env.pos_threshold == 0.01
+    _, _, d3, _ = env.step(a3)
+    assert d3 is True
+    with pytest.raises(ValueError):
+        env.g = (1.0, 0.0, -9.8)                        # only vertical gravity on the device path
+    with pytest.raises(ValueError):
+        env.ref_pos = (1.0, 2.0)
+    with pytest.raises(G._abi.RmavError):
+        env.mass = -1.0                                 # rmav_set_params validates
+    assert env.mass == 1.3
+    with pytest.raises(AttributeError):
+        env.load_mass                                   # noqa: B018 - Quadrotor3D has no load
+    env.close()
+    sl = G.make("quadrotor3d-slungload-v0", seed=4)
+    s0 = sl.reset()
+    sl.load_mass, sl.tether_length = 0.25, 1.0
+    q = O.default_params("quad3d_sl")
+    q.load_mass, q.tether_length = 0.25, 1.0
+    assert sl.load_mass == 0.25 and sl.tether_length == 1.0
+    a = sl.control()
+    ctrl_close(a, O.control("quad3d_sl", s0, q))
+    obs, r, d, _ = sl.step(a)
+    s1, r1, d1, _ = O.step("quad3d_sl", s0, a.astype(np.float32).astype(np.float64), None, q)
+    if abs(float(O.tether_slack("quad3d_sl", s0, q))) > 1e-5:
+        assert_close(obs, s1, STATE_TOL)
+    sl.close()
+    e2 = G.make("quadrotor2d-v0", seed=5)
+    e2.ref_pos = (0.5, -0.25)
+    e2.g = (0.0, -5.0)
+    p2 = O.default_params("quad2d")
+    p2.ref_pos[0], p2.ref_pos[1], p2.g = 0.5, -0.25, 5.0
+    s0 = e2.reset()
+    a = e2.control()
+    ctrl_close(a, O.control("quad2d", s0, p2))
+    e2.close()
+
+
 @pytest.mark.parametrize("numpy_io,lazy", [(False, False), (True, False), (False, True), (True, True)])
 def test_vec_env_contract(G, numpy_io, lazy):
     """lazy: the infos of a big batch (> 4 096 envs by default; forced here) are a list-like that is materialised on first use -
@@ -133,7 +223,8 @@ def test_vec_env_contract(G, numpy_io, lazy):
         if done.any():  # auto-reset: the returned obs of a finished env is its post-reset obs
             assert np.array_equal(obs[done], O.reset_states("quad3d", seed, np.nonzero(done)[0], rc[done]))
             for i in np.nonzero(done)[0]:
-                assert infos[i]["episode"]["l"] == ep_len[i]
+                assert infos[i]["episode"]["l"] == ep_len[i] and set(infos[i]["episode"]) == {"r", "l", "t"}   # Monitor's keys
+                assert 0.0 <= infos[i]["episode"]["t"] < 600.0
                 assert abs(infos[i]["episode"]["r"] - ep_ret[i]) < 1e-3
                 saw_episode = True
             ep_ret[done] = 0
@@ -151,6 +242,13 @@ def test_vec_env_contract(G, numpy_io, lazy):
         venv.step(a if numpy_io else torch.from_numpy(a).cuda())
         with pytest.raises(RuntimeError):
             old[0]
+        venv.step(a if numpy_io else torch.from_numpy(a).cuda())      # ... and stays an error two steps later (round 4 recycled two
+        with pytest.raises(RuntimeError):                             # objects, so an old reference answered for step s + 2)
+            old[0]
+        cur = venv.step(a if numpy_io else torch.from_numpy(a).cuda())[3]
+        i0 = int(np.nonzero(~np.asarray(cur._done if numpy_io else cur._done.cpu().numpy()))[0][0])
+        cur[i0]["mine"] = 1                                           # a wrapper writing into one env's info pollutes nothing
+        assert "mine" not in cur[i0 + 1 if i0 + 1 < n else i0 - 1] and all("mine" not in x for x in cur[:8])
     venv.close()
     big = G.QuadrotorVecEnv("quadrotor3d-v0", 8192, seed=seed)       # the default beyond 4 096 envs
     big.reset()

@@ -15,17 +15,66 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line(out):
-    lines = [l for l in out.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out[-3000:]
-    return json.loads(lines[0])
+    """The contract: the LAST stdout line is one JSON object of less than 4 KB (the driver keeps an 8 KB tail; round 4's
+    22 KB line was lost to it), and it is the only JSON line."""
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), out[-3000:]
+    assert len([l for l in lines if l.startswith("{")]) == 1, out[-3000:]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    return json.loads(lines[-1])
+
+
+def _detail(j):
+    path = os.path.join(ROOT, j["detail"])
+    assert os.path.exists(path), j["detail"]
+    return json.load(open(path))
+
+
+@pytest.mark.timeout(600)
+def test_bench_driver_command_line_is_compact(built, tmp_path):
+    """The driver's own command (python bench.py --gpus 1 --steps 20 --warmup 5, default legs): last stdout line < 4 KB with the
+    contract keys, roofline.frac and cpu_baseline.value; the per-step kernel has a roofline row at 65 536, 262 144 and 1 048 576 envs."""
+    import time
+
+    d = str(tmp_path / "detail.json")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--detail", d],
+                       capture_output=True, text=True, timeout=550, cwd=ROOT)
+    el = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = _line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "prewarm_ms", "prewarm_launches", "detail"):
+        assert k in j, k
+    assert j["steps"] == 20 and j["warmup"] == 5 and j["n_gpus"] == 1 and j["config"]["config_id"] == "C2"
+    rf = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_needed", "bytes_per_launch", "launch_ms_hip_events"):
+        assert k in rf, k
+    assert 0.0 < rf["frac"] <= 1.0 and rf["peak"] == 8000.0 and rf["bytes_per_launch"] == 65536 * (64 * 61 + 104)
+    cb = j["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 1 and cb["kind"] == "port" and cb["unit"] == "env-steps/s"
+    # timed region = steps x ms_per_step fits in the process's run time by a wide margin
+    assert j["steps"] * j["ms_per_step"] * 1e-3 < el
+    legs = j["legs"]
+    for k in ("step", "step_262144", "step_1048576", "sustained"):
+        assert 0.0 < legs[k]["frac"] <= 1.0, (k, legs[k])
+    mt = j["cpu_mt"]
+    assert mt["cores"] <= mt["cores_available"] and mt["value"] > 0
+    full = json.load(open(d))
+    assert full["other_modes"]["step_1048576"]["roofline"]["bytes_per_launch"] == 1048576 * 101
+    assert full["host_cpus"]["usable"] >= 1 and "cgroup_source" in full["host_cpus"]
+    assert len(r.stderr) < 2000, r.stderr[-2000:]     # stderr stays quiet: the driver's tail appends it to stdout's
 
 
 @pytest.mark.timeout(900)
 def test_bench_single_process_line(built):
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", "--cpu-seconds", "1"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "300", "--warmup", "50", "--cpu-seconds", "1", "--secondary", "all"],
                        capture_output=True, text=True, timeout=850, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    j = _line(r.stdout)
+    short = _line(r.stdout)
+    assert 0.0 < short["roofline"]["frac"] <= 1.0 and short["legs"]["c4"]["frac"] > 0 and short["legs"]["policy_rollout"]["bf16_mfma"]["value"] > 0
+    j = _detail(short)            # the full record: every leg in full
+    assert j["value"] == short["value"] and j["roofline"]["frac"] == short["roofline"]["frac"]
     assert j["n_gpus"] == 1 and j["steps"] == 300 and j["unit"] == "env-steps/s" and j["scaling"] == "weak"
     assert "configs[1]" in j["config"]["workload"] and j["config"]["envs_per_gpu"] == 65536
     assert j["config"]["trajectory_ring"] >= 5

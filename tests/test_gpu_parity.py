@@ -321,6 +321,66 @@ def test_fused_rollouts_repeat_bit_for_bit_at_four_wavefronts_per_simd(G, kind, 
             assert tot == tot0
 
 
+@pytest.mark.parametrize("kind", ["quad3d", "quad2d_sl"])
+def test_episode_lengths_across_launch_kinds_and_counter_moves(G, kind):
+    """Episode lengths are kept as 'step counter at episode start' (csrc/rmav_kernels.hpp: ep_clock0): single steps (eager and lazy
+    bookkeeping loads), fused rollouts, device-side and host-side reads, rmav_seed / rmav_set_step_count in between, an explicit
+    reset() - the running and the finished lengths always equal a host-side count driven by the returned `done` flags."""
+    import torch
+
+    n, lo, hi = 3000, *BOX[kind]
+    env = G.BatchedQuadrotor(kind, n, seed=4, auto_reset=True, track_episodes=True)
+    ln = np.zeros(n, np.int64)
+    last = np.zeros(n, np.int64)
+    fin_len = 0
+    rng = np.random.RandomState(2)
+
+    def account(done_TN):
+        nonlocal fin_len
+        for dk in np.asarray(done_TN).astype(bool):
+            ln[:] += 1
+            last[dk] = ln[dk]
+            fin_len += int(ln[dk].sum())
+            ln[dk] = 0
+
+    def check():
+        eb = env.episode_buffers()
+        assert np.array_equal(eb["cur_length"], ln), (eb["cur_length"][:8], ln[:8])
+        assert np.array_equal(eb["last_length"], last)
+        ed = env.episode_buffers(device_out=True)
+        assert np.array_equal(ed["cur_length"].cpu().numpy(), ln) and ed["cur_length"].dtype == torch.int32
+        assert env.episode_totals()["length_sum"] == fin_len
+
+    for phase in range(4):
+        env.set_tuning(step_lazy=phase % 2)
+        for _ in range(40):   # single steps: k_step
+            a = rng.uniform(lo, hi, (n, NA[kind])).astype(np.float32)
+            _, _, d = env.step(a)
+            account(d[None])
+        check()
+        tr = env.rollout(50, mode="random", layout="soa", fused=True, want=("done",))
+        account(tr["done"])
+        check()
+        tr = env.rollout(7, mode="random", layout="soa", fused=False, want=("done",))
+        account(tr["done"])
+        check()
+        if phase == 0:
+            env.step_count = 2 ** 32 - 20      # the 32-bit clock wraps inside the next phase
+        elif phase == 1:
+            env.seed(11)                       # rewinds the step counter to 0
+            assert env.step_count == 0
+        elif phase == 2:
+            env.step_count = 123456789012      # beyond 32 bits
+        check()
+    env.reset()
+    ln[:] = 0                                  # reset() starts a fresh episode (return and length), finished statistics stay
+    check()
+    _, _, d = env.step(rng.uniform(lo, hi, (n, NA[kind])).astype(np.float32))
+    account(d[None])
+    check()
+    env.close()
+
+
 @pytest.mark.parametrize("kind", KINDS)
 def test_single_step_variants_give_the_same_bits(G, kind):
     """rmav_step through k_step (batch- and feature-major), its write-through / non-temporal store variants, k_step with
@@ -671,11 +731,27 @@ def test_pitched_rollout_equals_the_plain_layout(G, kind, n, T, fused, mode):
     assert torch.equal(done[..., :n], ref["done"]) and bool((done[..., n:] == 77).all())
     assert np.array_equal(env.get_state(), ref_env.get_state()) and np.array_equal(env.get_reset_counts(), ref_env.get_reset_counts())
     assert env.episode_totals() == ref_env.episode_totals()
-    if mode != "buffer" and fused:   # the Python wrapper pitches by itself when N is not a multiple of 16
+    if mode != "buffer" and fused:
+        # the Python wrapper: plain contiguous tensors unless asked (round 4 pitched by itself and broke `out=` reuse and .view());
+        # pitched=True returns [..., :N] views, and handing those back as out= goes through the pitched entry point again
         env2 = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
-        tr = env2.rollout(T, mode=mode, layout="soa", want=("actions", "obs", "rew", "done"), device_out=True)
-        assert tr["obs"].stride(-2) == P and all(torch.equal(tr[k], ref[k]) for k in ("actions", "obs", "rew", "done"))
+        want = ("actions", "obs", "rew", "done")
+        plain = env2.rollout(T, mode=mode, layout="soa", want=want, device_out=True)
+        assert all(plain[k].is_contiguous() and torch.equal(plain[k], ref[k]) for k in want)
+        again = env2.rollout(T, mode=mode, layout="soa", want=want, device_out=True, out=plain)     # the allocate-then-reuse idiom
+        assert all(again[k].data_ptr() == plain[k].data_ptr() for k in want)
         env2.close()
+        env3 = G.BatchedQuadrotor(kind, n, seed=9, auto_reset=True, track_episodes=True)
+        tr = env3.rollout(T, mode=mode, layout="soa", want=want, device_out=True, pitched=True)
+        assert tr["obs"].stride(-2) == P and tr["rew"].stride(0) == P and all(torch.equal(tr[k], ref[k]) for k in want)
+        first = {k: v.clone() for k, v in tr.items()}
+        tr2 = env3.rollout(T, mode=mode, layout="soa", want=want, device_out=True, out=tr)           # pitched views handed back
+        assert all(tr2[k].data_ptr() == tr[k].data_ptr() for k in want)
+        ref2 = ref_env.rollout(T, mode=mode, layout="soa", want=want, device_out=True)
+        assert all(torch.equal(tr2[k], ref2[k]) for k in want) and not torch.equal(tr2["obs"], first["obs"])
+        with pytest.raises(ValueError):    # a mix of pitches is refused, not silently mis-addressed
+            env3.rollout(T, mode=mode, layout="soa", want=want, device_out=True, out=dict(tr, rew=torch.empty((T, n), device="cuda")))
+        env3.close()
     env.close()
     ref_env.close()
 

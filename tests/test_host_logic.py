@@ -80,12 +80,15 @@ def test_lazy_infos_list_contract():
             return {"last_return": np.arange(8, dtype=np.float32) * -1.5, "last_length": np.arange(8, dtype=np.int32) + 10}
 
     class FakeVec:
-        env, _info_seq = FakeBatch(), 3
+        env, _info_seq, _tstart = FakeBatch(), 3, 0.0
 
     done = np.array([0, 1, 0, 0, 0, 0, 1, 0], bool)
     infos = LazyInfos(8, done, FakeVec(), 3)
     assert len(infos) == 8 and not fetched
-    assert infos[1] == {"episode": {"r": -1.5, "l": 11}} and infos[-2]["episode"]["l"] == 16 and infos[0] == {}
+    assert set(infos[1]["episode"]) == {"r", "l", "t"} and infos[1]["episode"]["t"] > 0          # Monitor's keys
+    assert {k: infos[1]["episode"][k] for k in "rl"} == {"r": -1.5, "l": 11} and infos[-2]["episode"]["l"] == 16 and infos[0] == {}
+    infos[0]["x"] = 1                       # a write into one env's empty info touches no other env and no later read
+    assert infos[0] == {} and infos[2] == {} and all("x" not in i for i in infos)
     assert [bool(i.get("episode")) for i in infos] == list(done) and len(infos[2:5]) == 3 and len(fetched) == 1
     assert sorted(infos.finished()) == [1, 6]
     with pytest.raises(IndexError):

@@ -28,8 +28,9 @@ try:
     j = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
     r = j["roofline"]
     print("  ", sys.argv[1].split("/")[-1], round(j["value"] / 1e9, 2), "G/s", round(r["launch_ms_hip_events"] * 1e3, 2), "us/launch frac", round(r["frac"], 3))
-    for k, v in j.get("other_modes", {}).items():
+    for k, v in j.get("legs", {}).items():
         print("     ", k, json.dumps(v)[:400])
+    print("      line bytes:", len([l for l in open(sys.argv[1]) if l.startswith("{")][-1]), " cpu:", json.dumps(j.get("cpu_baseline", {}))[:200], json.dumps(j.get("cpu_mt", {})))
 except Exception as e:
     print("  ", sys.argv[1], "ERR", e)
 PY
@@ -45,8 +46,8 @@ base)
   timeout 2400 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu.log
   ;;
 bench)
-  timeout 900 $B > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "rc=$?"; line $OUT/bench_n1.json
-  timeout 900 $B --gpus 1 --steps 20 --warmup 5 > $OUT/bench_n1_k20.json 2> $OUT/bench_n1_k20.err; echo "rc=$?"; line $OUT/bench_n1_k20.json
+  timeout 900 $B --secondary all --detail $OUT/bench_n1_detail.json > $OUT/bench_n1.json 2> $OUT/bench_n1.err; echo "rc=$?"; line $OUT/bench_n1.json
+  ( time timeout 900 $B --gpus 1 --steps 20 --warmup 5 --detail $OUT/bench_n1_k20_detail.json > $OUT/bench_n1_k20.json 2> $OUT/bench_n1_k20.err ) 2>&1 | grep real; line $OUT/bench_n1_k20.json
   ;;
 legs)
   timeout 600 $B --envs-per-gpu 131072 --cpu-seconds 0 --no-secondary > $OUT/bench_c3shard.json 2>/dev/null; line $OUT/bench_c3shard.json
