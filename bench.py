@@ -430,7 +430,7 @@ def main():
         if tune:
             env.set_tuning(**tune)
         gloo = use_dist and dist.get_backend() == "gloo"
-        exchange, exchange_kind, native_abandoned = None, None, False
+        exchange, exchange_kind, native_abandoned, comm_info = None, None, False, None
         if use_dist:
             # the collective behind the C ABI (RCCL from librmav's own stream, ~15 us of host time per post); every rank must
             # take the same path, so fall back together to the torch.distributed exchange if any rank cannot set it up
@@ -452,6 +452,10 @@ def main():
                 ok = int(flag.item())
             if ok:
                 exchange_kind = "rmav_allgather_stats_post/_result (RCCL from librmav.so, own stream)"
+                try:   # what the collective library itself says about the communicator (ncclCommCount / ncclCommUserRank)
+                    comm_info = exchange.info()
+                except Exception as e:  # pragma: no cover
+                    comm_info = {"error": repr(e)}
             else:
                 if exchange is not None:
                     exchange.close()
@@ -754,6 +758,7 @@ def main():
                 "finished_episodes": totals["episodes"],
                 "gathered_envs_with_a_finished_episode": gathered_finished,
                 "exchange_equals_plain_all_gather": exchange_check,
+                "rccl_ranks": (comm_info or {}).get("lib_world"),   # ncclCommCount of the library's own communicator (None: torch's exchange)
             },
             "roofline": roof,
         }
@@ -811,7 +816,10 @@ def main():
             r_ = v.get("roofline")
             if isinstance(r_, dict) and "frac" in r_:
                 row["frac"] = round(r_["frac"], 4)
-                row["us"] = round(1e3 * r_["launch_ms_hip_events"], 3)
+                row["bound"] = r_.get("bound", "hbm")
+                ms_ = r_.get("launch_ms_hip_events", v.get("ms_per_launch_hip_events"))
+                if ms_:
+                    row["us"] = round(1e3 * ms_, 3)
                 if r_.get("traffic_over_needed"):
                     row["traffic_over_needed"] = round(r_["traffic_over_needed"], 3)
             elif "roofline_frac" in v:

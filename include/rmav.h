@@ -353,6 +353,10 @@ int rmav_comm_use_library(const char *path);
 int rmav_comm_unique_id(void *id_out /* RMAV_COMM_ID_BYTES bytes, host */);
 int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device);
 int rmav_comm_destroy(rmav_comm c);
+/* What the communicator is: rank / world as passed to rmav_comm_create, and what the collective library itself reports for its
+ * communicator (ncclCommUserRank / ncclCommCount; -1 when the library does not export them).  Any pointer may be NULL.  Lets a
+ * launcher assert that RCCL really connected `world` ranks (the role of the MPI rank probe of gym_reinmav/run.py:18-21,177-182). */
+int rmav_comm_info(rmav_comm c, int *rank_out, int *world_out, int *lib_rank_out, int *lib_world_out);
 /* One tiny all-gather on the communicator's own stream, awaited on the HOST for at most timeout_s seconds (< 0: no limit):
  * RMAV_OK, or RMAV_ERR_TIMEOUT.  RCCL connects its transports inside the FIRST collective's enqueue - a host-side exchange
  * with the peers that blocks when one of them is gone - so a caller that wants a bounded set-up runs rmav_comm_create +

@@ -285,17 +285,41 @@ template <int K> int launch_rollout_k(rmav_handle h, int mode, const RolloutArgs
     return rmav_fail(RMAV_ERR_INVALID, "unknown action_mode %d", mode);
 }
 
+// k_step's launch rules by batch size (profiles/r05/step_sweep.md; every variant writes the same bits).  Up to ~196 608 envs a
+// launch is mostly launch latency: eager bookkeeping loads (a dependent round trip costs more than the 12 B it saves), 256-thread
+// workgroups, write-back stores.  Up to ~786 432 envs: non-temporal stores (7.0 -> 6.7-6.9 us at 262 144).  Beyond: bookkeeping
+// loaded only in lanes whose env terminates and 128-thread workgroups (1 048 576 envs 26.4 -> 23.5 us, 4 194 304: 92.9 -> 78.9).
+// rmav_set_tuning(RMAV_TUNE_STEP_LAZY | _BLOCK | _STEP_STORE) overrides each.
+inline bool step_lazy(rmav_handle h) {
+    const int t = h->tune[RMAV_TUNE_STEP_LAZY];
+    return t >= 0 ? t == 1 : h->n >= 786432;
+}
+inline int step_block(rmav_handle h) {
+    const int v = h->tune[RMAV_TUNE_BLOCK];
+    return (v == 64 || v == 128 || v == 256) ? v : (h->n >= 786432 ? 128 : 256);
+}
+inline int step_store(rmav_handle h) {
+    const int v = h->tune[RMAV_TUNE_STEP_STORE];
+    return v >= 0 ? v : ((h->n >= 196608 && h->n < 786432) ? (int)ST_STREAM : (int)ST_DEFAULT);
+}
+
 // n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_TUNE_STEP_KERNEL = 0 falls back to k_rollout)
 template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctrl) {
     if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;   // the armed launch's snapshot is no longer the latest
     const typename Env<K>::P p = derive_env<K>(h->params);
     const ParamsT<double> pc = derive<double>(h->params);
-    const int st = h->tune[RMAV_TUNE_STEP_STORE];
-    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
-    else if (h->tune[RMAV_TUNE_STEP_LAZY] == 1) hipLaunchKernelGGL((k_step<K, false, true>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
-    else if (st == ST_WRITE_THROUGH) hipLaunchKernelGGL((k_step<K, false, false, ST_WRITE_THROUGH>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
-    else if (st == ST_STREAM) hipLaunchKernelGGL((k_step<K, false, false, ST_STREAM>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
-    else hipLaunchKernelGGL((k_step<K, false>), grid_for(h), dim3(block_size(h)), 0, h->stream, a, p, pc);
+    const int st = step_store(h), bs = step_block(h);
+    const bool lazy = step_lazy(h);
+    const dim3 grid((unsigned)((h->n + bs - 1) / bs));
+#define RMAV_STEP(LAZY, ST) hipLaunchKernelGGL((k_step<K, false, LAZY, ST>), grid, dim3(bs), 0, h->stream, a, p, pc)
+    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid, dim3(bs), 0, h->stream, a, p, pc);
+    else if (lazy && st == ST_STREAM) RMAV_STEP(true, ST_STREAM);
+    else if (lazy && st == ST_WRITE_THROUGH) RMAV_STEP(true, ST_WRITE_THROUGH);
+    else if (lazy) RMAV_STEP(true, ST_DEFAULT);
+    else if (st == ST_WRITE_THROUGH) RMAV_STEP(false, ST_WRITE_THROUGH);
+    else if (st == ST_STREAM) RMAV_STEP(false, ST_STREAM);
+    else RMAV_STEP(false, ST_DEFAULT);
+#undef RMAV_STEP
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
@@ -1224,6 +1248,8 @@ struct RcclApi {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;      // optional (rmav_comm_info)
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;   // optional
 };
 // resolved on first use: librmav.so has no link-time dependency on RCCL, and a process that already loaded
 // librccl.so.1 (torch does) shares that copy
@@ -1247,6 +1273,8 @@ RcclApi *rccl() {
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
             api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+            api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
             if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather) api.lib = nullptr;
         }
     }
@@ -1276,6 +1304,19 @@ int rmav_comm_unique_id(void *id_out) {
     RCCL_TRY(R->GetUniqueId(&id));
     static_assert(sizeof(id) == RMAV_COMM_ID_BYTES, "RCCL unique id size");
     memcpy(id_out, &id, sizeof(id));
+    return RMAV_OK;
+}
+
+int rmav_comm_info(rmav_comm c, int *rank_out, int *world_out, int *lib_rank_out, int *lib_world_out) {
+    if (!c || c->magic != kCommMagic) return rmav_fail(RMAV_ERR_INVALID, "invalid rmav_comm");
+    if (rank_out) *rank_out = c->rank;
+    if (world_out) *world_out = c->world;
+    RcclApi *R = rccl();
+    int lr = -1, lw = -1;
+    if (R && R->CommUserRank && R->CommUserRank(c->comm, &lr) != ncclSuccess) lr = -1;
+    if (R && R->CommCount && R->CommCount(c->comm, &lw) != ncclSuccess) lw = -1;
+    if (lib_rank_out) *lib_rank_out = lr;
+    if (lib_world_out) *lib_world_out = lw;
     return RMAV_OK;
 }
 

@@ -1,15 +1,14 @@
 // rmav_policy_abi.hip - launches of the policy-in-kernel rollouts (rmav_rollout_policy); the second translation unit of librmav.so.
 //
 // Compiled with -fno-slp-vectorize.  hipcc's SLP vectoriser packs adjacent scalar fp32 operations of the dynamics into
-// v_pk_mul / v_pk_fma / v_pk_add_f32 / v_pk_mov_b32 with cross-register op_sel selects.  In kernels that also issue MFMAs, with
-// more than one such wavefront per SIMD, a read one or two instructions behind such a packed write returned the register's
-// PREVIOUS contents in lanes 48..63 (profiles/r04/packed_f32_hazard.md: x-axis thrust term of quadrotor3d's step lost,
-// 7 - 25 % of the wavefronts of an f16-actor rollout, ~1 % for bf16, ~0.1 % for round 3's one-wavefront bf16 kernel at
-// 262 144 envs; never with one wavefront per SIMD, never in the MFMA-free kernels, which tests and tools/determinism.py
-// cover at 2 - 4 wavefronts per SIMD).  Without the vectoriser: 0 differing bits in 40 rollouts of every variant, and the
-// kernels are no slower (packed fp32 beside MFMAs costs more than it saves, /opt/skills/guides/MI355X_MICROARCH.md).
-// tests/test_gpu_ppo.py::test_matrix_core_actors_are_deterministic guards it; tests/test_resource_usage.py pins that these
-// kernels contain no compiler-made packed fp32 arithmetic.
+// v_pk_mul / v_pk_fma / v_pk_add_f32 with cross-register op_sel selects, among them `v_pk_fma_f32 D, P, Q, D op_sel:[0,1,0]`
+// (quat_body_z).  On gfx950 the operand that op_sel[1] = 1 selects - the HIGH dword of src1 for the LOW result - reads as ZERO in
+// lanes 48..63 while a v_mfma_f32_32x32x16_{f16,bf16} of any wavefront executes on the same SIMD: the x-axis thrust term of
+// quadrotor3d's step was lost in 1 - 25 % of the wavefronts of a rollout, never with one wavefront per SIMD (three rounds of parity
+// tests at BASELINE sizes were green).  Root cause, wait-state sweep (they do not help), flag A/B (the stock build fails as
+// well) and the 148-line stand-alone reproducer: profiles/r05/packed_f32_hazard.md, tools/micro/pk_hazard.hip.  The Makefile
+// disassembles every object and refuses to build one that contains the form (`check_isa`);
+// tests/test_gpu_ppo.py::test_matrix_core_actors_are_deterministic and tests/test_resource_usage.py guard it as well.
 #include "rmav_handle.hpp"
 #include "rmav_policy_pair.hpp"
 

@@ -112,14 +112,10 @@ __device__ __forceinline__ void scale_biases_for_tanh() {
 
 // Value of lane l ^ 32 - WITHOUT ds_bpermute.  v_permlane32_swap (gfx950) exchanges the upper half of one register with the
 // lower half of another inside the vector ALU: two instructions per value and no trip through the LDS crossbar (~50+ cycles).
-// It is also a correctness matter here (profiles/r04/mfma_bpermute_hazard.md): with __shfl_xor (= ds_bpermute_b32) behind the
-// MFMA chain and more than one MFMA-issuing wavefront per SIMD, a vector instruction that overwrote the B fragment of an
-// already executed v_mfma_f32_32x32x16 was followed, four instructions later, by a read that still returned the OLD register
-// contents in lanes 48..63 (the last quarter the LDS return path writes): ~10 of 1 024 wavefronts per 32-step rollout with two
-// (actor, critic) pairs per workgroup, ~1 per rollout for round 3's one-wavefront kernel at 262 144 envs, never with one
-// wavefront per SIMD.  Neither hipcc's wait states nor a dependent read of the last MFMA's last register removed it; taking
-// the LDS instruction out of the matrix-core kernels did (0 in 40 rollouts), and tests/test_gpu_ppo.py::
-// test_matrix_core_actors_are_deterministic repeats every variant at 2-4 wavefronts per SIMD.
+// (Round 4 also credited this change with removing the stale reads in lanes 48..63 of these kernels.  It only moved the
+// instruction streams: the cause is a packed-fp32 instruction with op_sel on src1 beside a 32x32x16 MFMA - root-caused in round 5,
+// profiles/r05/packed_f32_hazard.md, reproducer tools/micro/pk_hazard.hip - and the fix is that no object of this library may
+// contain that instruction form: -fno-slp-vectorize + the `check_isa` step of the Makefile, which fails the build otherwise.)
 __device__ __forceinline__ float xor32(float v) {
     const uint32_t x = __builtin_bit_cast(uint32_t, v);
     const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);   // r[0]: the low half in both halves, r[1]: the high half

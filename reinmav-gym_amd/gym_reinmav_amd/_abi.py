@@ -109,6 +109,7 @@ PROTOTYPES = {
     "rmav_comm_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "rmav_comm_destroy": (C.c_int, [C.c_void_p]),
     "rmav_comm_warmup": (C.c_int, [C.c_void_p, C.c_double]),
+    "rmav_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rmav_allgather_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, _fp, _vp]),
     "rmav_allgather_stats_post": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "rmav_allgather_stats_arm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),

@@ -224,6 +224,14 @@ class NativeStatsExchange:
         A.check(rc)
         self.result()
 
+    def info(self) -> dict:
+        """{'rank', 'world'} as created and {'lib_rank', 'lib_world'} = what the collective library reports for its communicator
+        (ncclCommUserRank / ncclCommCount; -1 if it does not export them)."""
+        C, A = self._C, self._A
+        v = [C.c_int(-1) for _ in range(4)]
+        A.check(A.lib().rmav_comm_info(self._comm, *[C.byref(x) for x in v]))
+        return dict(zip(("rank", "world", "lib_rank", "lib_world"), (x.value for x in v)))
+
     def arm(self, env=None):
         """Call BEFORE the rollout whose statistics the next post() exchanges: that launch then writes the snapshot itself
         and post() adds nothing to the env's stream (rmav_allgather_stats_arm)."""

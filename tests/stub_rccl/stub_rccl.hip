@@ -142,6 +142,17 @@ ncclResult_t ncclAllGather(const void *send, void *recv, size_t count, ncclDataT
     return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
+ncclResult_t ncclCommCount(const ncclComm_t comm, int *count) {
+    if (!comm || !count) return ncclInvalidArgument;
+    *count = ((Comm *)comm)->world;
+    return ncclSuccess;
+}
+ncclResult_t ncclCommUserRank(const ncclComm_t comm, int *rank) {
+    if (!comm || !rank) return ncclInvalidArgument;
+    *rank = ((Comm *)comm)->rank;
+    return ncclSuccess;
+}
+
 const char *ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : g_last; }
 
 }  // extern "C"

@@ -185,7 +185,37 @@ def test_bench_two_gpus_native_exchange(built):
     j1 = _line(r1.stdout)
     assert j2["n_gpus"] == 2 and j2["config"]["envs_total"] == 131072 == j1["config"]["envs_total"]
     assert "rmav_allgather_stats_post" in j2["config"]["parallelism"], j2["config"]["parallelism"]
+    assert j2["config"]["rccl_ranks"] == 2
     assert j2["config"]["exchange_equals_plain_all_gather"] is True
     assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
     assert 0.0 < j2["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.timeout(1800)
+def test_bench_eight_gpus_is_baseline_c3(built):
+    """Needs 8 GPUs (self-skips elsewhere): `bench.py --gpus 8 --envs-per-gpu 131072` IS BASELINE configs[2] (C3: 1 048 576 envs as 8
+    contiguous shards) - native exchange, RCCL reports 8 ranks, the gathered statistics equal a plain all-gather; and the driver's
+    own weak-scaling command (`--gpus 8`, 65 536 envs per GPU) carries the C3 leg.  No rate is asserted: the first real scaling
+    curve must need zero edits, nothing more."""
+    import torch
+
+    if torch.cuda.device_count() < 8:
+        pytest.skip("needs 8 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for extra, cid in ((["--envs-per-gpu", "131072"], "C3"), ([], "C2x8")):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "200", "--warmup", "50",
+                            "--cpu-seconds", "0"] + extra, capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        j = _line(r.stdout)
+        c = j["config"]
+        assert j["n_gpus"] == 8 and c["config_id"] == cid and c["envs_total"] == 8 * c["envs_per_gpu"]
+        assert "rmav_allgather_stats_post" in c["parallelism"], c["parallelism"]
+        assert c["rccl_ranks"] == 8 and c["exchange_equals_plain_all_gather"] is True
+        assert c["gathered_envs_with_a_finished_episode"] > 0 and 0.0 < j["roofline"]["frac"] <= 1.0
+        if cid == "C2x8":
+            assert j["legs"]["c3"]["envs_total"] == 1048576 and _detail(j)["other_modes"]["c3"]["is_baseline_config_2"] is True

@@ -187,6 +187,7 @@ def test_bench_two_ranks_one_gpu_native_exchange(stub):
     j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
     assert j2["n_gpus"] == 2 and j2["config"]["envs_total"] == 32768 == j1["config"]["envs_total"]
     assert "rmav_allgather_stats_post" in j2["config"]["parallelism"], j2["config"]["parallelism"]
+    assert j2["config"]["rccl_ranks"] == 2          # rmav_comm_info -> the collective library's own ncclCommCount
     assert j2["config"]["exchange_equals_plain_all_gather"] is True
     assert j2["config"]["finished_episodes"] == j1["config"]["finished_episodes"] > 0
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
@@ -206,6 +207,11 @@ def test_bench_multi_gpu_line_carries_the_c3_leg(stub):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["config"]["envs_per_gpu"] == 65536 and j["scaling"] == "weak"
-    c3 = j["other_modes"]["c3"]
+    last = [l for l in r.stdout.splitlines() if l.strip()][-1]
+    assert last.startswith("{") and len(last) < 4096                       # the compact line, also for N > 1
+    assert j["config"]["config_id"] == "C2x2"
+    row = j["legs"]["c3"]                                                  # short row in the line ...
+    assert row["envs_total"] == 2 * 131072 and row["value"] > 0 and 0.0 < row["frac"] <= 1.0
+    c3 = json.load(open(os.path.join(ROOT, j["detail"])))["other_modes"]["c3"]   # ... the full leg in the detail file
     assert c3["envs_total"] == 2 * 131072 and c3["value"] > 0 and 0.0 < c3["roofline_frac_slowest_rank"] <= 1.0
     assert c3["is_baseline_config_2"] is False

@@ -84,11 +84,17 @@ def test_pair_actors_fit_two_wavefronts_per_simd(usage):
 
 
 def test_matrix_core_kernels_have_no_lds_permutes_and_no_compiler_packed_fp32():
-    """The policy-in-kernel rollouts are built without the SLP vectoriser and exchange lanes with v_permlane32_swap
-    (csrc/rmav_policy_abi.hip, csrc/rmav_policy_mfma.hpp: two measured sources of stale register reads in lanes 48..63 when
-    several MFMA-issuing wavefronts share a SIMD).  The hand-written packed operations of the activations are
-    v_pk_add_f32 / v_pk_fma_f32 with scalar constants; v_pk_mul_f32 / v_pk_mov_b32 only ever came from the vectoriser."""
+    """gfx950 hazard, root-caused in round 5 (profiles/r05/packed_f32_hazard.md, tools/micro/pk_hazard.hip): a packed-fp32 instruction whose
+    op_sel selects the HIGH half of src1 for the low result reads zero in lanes 48..63 while a v_mfma_f32_32x32x16_{f16,bf16} executes on
+    the SIMD.  Only the SLP vectoriser emits that form, so NO kernel of the library may contain it (both translation units are built with
+    -fno-slp-vectorize, and the Makefile's check_isa step refuses an object that has it).  The matrix-core kernels additionally stay free
+    of v_pk_mul_f32 / v_pk_mov_b32 (compiler-only forms) and of LDS permutes (lanes are exchanged with v_permlane32_swap)."""
     subprocess.run(["make", "-s", "-C", PKG, "asm"], check=True)
+    bad_form = re.compile(r"v_pk_(fma|mul|add)_f32 .*op_sel:\[[01],1")
+    for unit in ("rmav_abi", "rmav_policy_abi"):
+        txt = open(os.path.join(PKG, "build", unit + ".gfx950.s")).read()
+        hits = bad_form.findall(txt)
+        assert not hits, (unit, len(hits))
     txt = open(os.path.join(PKG, "build", "rmav_policy_abi.gfx950.s")).read()
     bodies = re.split(r"^(_ZN4rmav\w+):[^\n]*\n", txt, flags=re.M)   # [pre, name, body, name, body, ...]
     seen = 0
@@ -101,6 +107,17 @@ def test_matrix_core_kernels_have_no_lds_permutes_and_no_compiler_packed_fp32():
             assert bad not in body, (name, bad)
     assert seen >= 26, seen   # 10 + 5 pair kernels, 5 + 5 one-wavefront bf16 / fp32-MFMA kernels, mlp_mfma
     assert txt.count("v_permlane32_swap") >= 100 and txt.count("v_mfma_f32_32x32x16_f16") >= 100
+
+
+def test_makefile_refuses_an_object_with_the_hazardous_instruction_form(tmp_path):
+    """The check_isa step: building the policy translation unit WITH the SLP vectoriser must fail, not produce a library."""
+    r = subprocess.run(["make", "-C", PKG, "build/rmav_policy_abi.o", "-B", "HIPFLAGS=--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC"],
+                       capture_output=True, text=True)
+    try:
+        assert r.returncode != 0 and "refusing to build" in r.stdout + r.stderr, (r.stdout[-500:], r.stderr[-500:])
+        assert not os.path.exists(os.path.join(PKG, "build", "rmav_policy_abi.o"))
+    finally:   # put the real object back (the library itself was not relinked: only the one target was requested)
+        subprocess.run(["make", "-s", "-C", PKG], check=True)
 
 
 def _kernel_asm(prefix, which="rmav_abi"):

@@ -3,13 +3,13 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they need 3 + 2; no --stats with --pmc).
 # Usage (via gpurun, from the repo root): bash tools/profile_round.sh <tag> [round]     e.g.  r03_p r03
 # Writes gpurun_out/<tag>/prof/{summary.md, traffic.json, trace_*, pmc_*}; tools/collect_profiles.sh copies the judged files.
-TAG=${1:-r03_p}; ROUND=${2:-r03}
+TAG=${1:-r05_p}; ROUND=${2:-r05}
 OUT=$PWD/gpurun_out/$TAG/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-B="python $REPO/bench.py --no-secondary --cpu-seconds 0"
+B="python $REPO/bench.py --no-secondary --cpu-seconds 0 --detail -"
 run() {  # name, rocprof args..., -- cmd
   local name=$1; shift
   echo "== $name"
@@ -22,6 +22,8 @@ CASES=(
   "c2_inplace|--in-place"
   "c2_step|--mode step --steps 3000 --warmup 300"
   "c2_step_lazy|--mode step --steps 3000 --warmup 300 --tune step_lazy=1"
+  "step_262144|--mode step --envs-per-gpu 262144 --steps 2000 --warmup 300"
+  "step_1048576|--mode step --envs-per-gpu 1048576 --steps 800 --warmup 200"
   "c3shard_ring|--envs-per-gpu 131072 --steps 1000 --warmup 100"
   "c4_ring|--kind quad3d_sl --envs-per-gpu 262144 --steps 400 --warmup 50"
 )
@@ -29,7 +31,7 @@ CASES=(
 # ReinmavEnv (k_rollout<4, 2, 0>) and the policy-in-kernel rollouts of C5's per-GPU shape (k_rollout<2, 3|8|4, 0>, k_rollout_pair<2, *>,
 # k_rollout_pair_shared<2>) - traced under the driver's own command line, so that the averages are comparable with other_modes.*
 if [ -z "$ONLY" ] || [[ " $ONLY " =~ " legs " ]]; then
-  run trace_legs --kernel-trace --stats --output-format csv -d $OUT/trace_legs -- python $REPO/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary c4_pe,reinmav,policy
+  run trace_legs --kernel-trace --stats --output-format csv -d $OUT/trace_legs -- python $REPO/bench.py --steps 20 --warmup 5 --cpu-seconds 0 --secondary c4_pe,reinmav,policy --detail -
 fi
 for c in "${CASES[@]}"; do
   name=${c%%|*}; args=${c#*|}
