@@ -359,9 +359,9 @@ def test_bf16_pair_kernel_equals_the_one_wavefront_kernel(G, kind, n):
                                            ("bf16_1w", 131072, {}), ("bf16_1w", 262144, {}), ("fp32_mfma", 65536, {}), ("fp32_mfma", 131072, {})])
 def test_matrix_core_actors_are_deterministic(G, actor, n, tune):
     """Every matrix-core actor, at 2 - 4 wavefronts per SIMD, five 32-step rollouts from the same state: bit-identical outputs.
-    (Round 4 found ~1 % of the wavefronts of such launches reading a stale register in lanes 48..63 when the lane exchange
-    behind the MFMA chain was a ds_bpermute - csrc/rmav_policy_mfma.hpp, xor32; one wavefront per SIMD never showed it, so the
-    parity tests at 65 536 envs could not.)"""
+    (Round 4 found ~1 - 25 % of the wavefronts of such launches with wrong physics in lanes 48..63; round 5's root cause: a
+    compiler-made packed-fp32 instruction with op_sel on src1 reads zero there while a 32x32x16 MFMA executes on the SIMD -
+    profiles/r05/packed_f32_hazard.md.  One wavefront per SIMD never showed it, so the parity tests at 65 536 envs could not.)"""
     import torch
     from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
 
@@ -390,6 +390,50 @@ def test_matrix_core_actors_are_deterministic(G, actor, n, tune):
             bad = (x != y)
             assert not bool(bad.any()), (rep, int(bad.sum()), sorted(set((bad.nonzero()[:, -1] % 64).tolist()))[:4])
         assert tot == tot0
+
+
+@pytest.mark.parametrize("kind,n,mode", [("quad3d", 65536, "random"), ("quad3d", 262144, "random"), ("quad3d", 131072, "controller"),
+                                         ("quad3d_sl", 65536, "random"), ("quad2d", 65536, "random")])
+def test_mfma_free_rollouts_are_bit_stable_beside_matrix_core_work(G, kind, n, mode):
+    """The hazard of profiles/r05/packed_f32_hazard.md needs a 32x32x16 MFMA on the SIMD - from ANY wavefront, also another stream's:
+    with the SLP-vectorised build of rounds 1 - 4 the MFMA-free quadrotor3d rollout (the headline kernel) lost its x-axis thrust term
+    in 12 - 46 wavefronts per launch at 65 536 envs and 500 - 900 at 262 144 while the f16 policy rollout of another env ran on a
+    second stream (hazard_concurrent_streams.txt).  Fused rollouts alone give the reference bits; the same rollouts with ~6 ms of
+    matrix-core work queued on the other stream must give exactly those."""
+    import torch
+    from gym_reinmav_amd.ppo import FusedPolicyCollector, MlpPolicy
+
+    T, want = 64, ("actions", "obs", "rew", "done")
+    s_env, s_mfma = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.cuda.stream(s_mfma):
+        penv = G.BatchedQuadrotor("quad3d", 65536, seed=3)
+        torch.manual_seed(1)
+        ro = FusedPolicyCollector(penv, MlpPolicy(penv.nS, penv.nA).cuda(), 32, f16_mfma=True)
+        ro.collect()
+    torch.cuda.synchronize()
+
+    def run(beside):
+        with torch.cuda.stream(s_env):
+            env = G.BatchedQuadrotor(kind, n, seed=7)
+            if beside:
+                with torch.cuda.stream(s_mfma):
+                    for _ in range(40):
+                        ro.collect()
+            tr = env.rollout(T, mode=mode, layout="soa", want=want, device_out=True)
+            tr = env.rollout(T, mode=mode, layout="soa", want=want, device_out=True, out=tr)
+            s_env.synchronize()
+            out = [tr[k].clone() for k in want] + [env.get_state(layout="soa", device_out=True).clone()]
+            env.close()
+        torch.cuda.synchronize()
+        return out
+
+    ref = run(False)
+    for rep in range(4):
+        for x, y in zip(run(True), ref):
+            bad = x != y
+            assert not bool(bad.any()), (rep, int(bad.sum()), sorted(set((bad.nonzero()[:, -1] % 64).tolist()))[:4])
+    with torch.cuda.stream(s_mfma):
+        penv.close()
 
 
 @pytest.mark.parametrize("actor", ["fp32", "fp32_mfma", "bf16", "f16", "f16_shared"])
