@@ -26,7 +26,7 @@
 #include <unistd.h>
 
 namespace {
-constexpr int MAXR = 4, SLOTS = 4;
+constexpr int MAXR = 8, SLOTS = 4;   // up to 8 rank processes on the one GPU (the shape of an 8-GPU node's launch)
 constexpr size_t MAXBYTES = 5u << 18;   // 1.25 MiB per rank and call (BASELINE C3's payload is 1 MiB)
 struct Shm {
     std::atomic<uint32_t> joined, left;

@@ -193,6 +193,36 @@ def test_bench_two_ranks_one_gpu_native_exchange(stub):
     assert j2["config"]["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
 
 
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_one_gpu_is_the_eight_gpu_launch(stub):
+    """The driver's 8-GPU command line - `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` - with eight rank PROCESSES on
+    the one GPU (stub collective library, gloo process group): shards by global env id, native exchange with world = 8
+    (rmav_comm_info reports 8 ranks), gathered statistics equal a plain all-gather, and the sharded run finishes exactly the episodes
+    of the unsharded one.  What a real 8-GPU node adds is RCCL's transports and seven more devices - no code path of ours."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    common = ["--steps", "16", "--warmup", "4", "--prewarm-ms", "0", "--cpu-seconds", "0", "--no-secondary", "--chunk", "32"]
+    env = dict(os.environ, RMAV_BENCH_BACKEND="gloo", RMAV_BENCH_RCCL_LIB=STUB, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r8 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                         "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8",
+                         "--envs-per-gpu", "8192"] + common, capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert r8.returncode == 0, r8.stdout[-2000:] + r8.stderr[-3000:]
+    last = [l for l in r8.stdout.splitlines() if l.strip()][-1]
+    assert last.startswith("{") and len(last) < 4096
+    j8 = json.loads(last)
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs-per-gpu", "65536"] + common,
+                        capture_output=True, text=True, timeout=850, cwd=ROOT)
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-3000:]
+    j1 = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])
+    c = j8["config"]
+    assert j8["n_gpus"] == 8 and c["envs_total"] == 65536 == j1["config"]["envs_total"] and j8["scaling"] == "weak"
+    assert "rmav_allgather_stats_post" in c["parallelism"] and c["rccl_ranks"] == 8
+    assert c["exchange_equals_plain_all_gather"] is True
+    assert c["finished_episodes"] == j1["config"]["finished_episodes"] > 0
+    assert c["gathered_envs_with_a_finished_episode"] == j1["config"]["gathered_envs_with_a_finished_episode"] > 0
+
+
 @pytest.mark.timeout(900)
 def test_bench_multi_gpu_line_carries_the_c3_leg(stub):
     """Without --no-secondary a multi-rank bench line also measures BASELINE configs[2]'s shape: 131 072 envs on every rank,
