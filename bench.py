@@ -235,7 +235,7 @@ def roofline_obj(bytes_launch: float, launch_ms: float, traffic, traffic_src, de
 
 
 def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, label: str, tune=None, per_env_params=False,
-                cpu_seconds: float = 0.0, env_id_base: int = 0, before_timed=None):
+                cpu_seconds: float = 0.0, env_id_base: int = 0, before_timed=None, chunk_major=False):
     """One more single-GPU BASELINE config as its own short measurement: fused random-action rollouts of `kind` over `n` envs
     into a cold ring of trajectory buffer sets, timed with HIP events on the launch stream (same method as the headline).
     per_env_params: every env gets its own mass / load mass / tether length (rmav_set_env_param: SURVEY 8f-4, the constants
@@ -255,10 +255,13 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
             pr = env.params
             for name, base in (("mass", pr.mass), ("load_mass", pr.load_mass), ("tether_length", pr.tether_length)):
                 env.set_env_param(name, (base * (0.9 + 0.2 * torch.rand(n, generator=gen))).to(torch.float32).numpy())
-        ring = [{"actions": torch.zeros((chunk, nA, n), dtype=torch.float32, device=dev),
-                 "obs": torch.zeros((chunk, nS, n), dtype=torch.float32, device=dev),
-                 "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
-                 "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev)} for _ in range(R)]
+        ce = int(env._lib.rmav_chunk_envs(env._h)) if chunk_major else n     # chunk-major trajectories: rmav_rollout_chunked (include/rmav.h)
+        nc = -(-n // ce)
+        shp = (lambda d: (nc, chunk, d, ce)) if chunk_major else (lambda d: (chunk, d, n))
+        ring = [{"actions": torch.zeros(shp(nA), dtype=torch.float32, device=dev),
+                 "obs": torch.zeros(shp(nS), dtype=torch.float32, device=dev),
+                 "rew": torch.zeros((nc, chunk, ce) if chunk_major else (chunk, n), dtype=torch.float32, device=dev),
+                 "done": torch.zeros((nc, chunk, ce) if chunk_major else (chunk, n), dtype=torch.uint8, device=dev)} for _ in range(R)]
         it = 0
         for phase, count in (("warm", W), ("timed", K)):
             if phase == "timed":
@@ -269,8 +272,11 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
                 t0 = time.perf_counter()
                 e0.record(stream)
             for _ in range(count):
-                env.rollout(chunk, mode="random", layout="soa", fused=True, want=("actions", "obs", "rew", "done"),
-                            device_out=True, out=ring[it % R])
+                if chunk_major:
+                    env.rollout_chunked(chunk, mode="random", chunk=ce, want=("actions", "obs", "rew", "done"), out=ring[it % R])
+                else:
+                    env.rollout(chunk, mode="random", layout="soa", fused=True, want=("actions", "obs", "rew", "done"),
+                                device_out=True, out=ring[it % R])
                 it += 1
         e1.record(stream)
         stream.synchronize()
@@ -281,9 +287,10 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
     del ring
     torch.cuda.empty_cache()
     b = fused_bytes_per_launch(n, chunk, nS, nA) + (12 * n if per_env_params else 0)
-    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa" + (":pe" if per_env_params else ""))
+    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa" + (":pe" if per_env_params else "") + (":chunked" if chunk_major else ""))
     out = {"workload": f"{label}: {ENV_ID[kind]}, {n} envs, random actions, auto-reset, episode tracking; {chunk}-step fused launches "
                        f"into a ring of {R} trajectory buffer sets ({R * per_set / 1e9:.2f} GB: cold stores)" +
+                       (f"; CHUNK-MAJOR trajectory arrays [{nc}][{chunk}][dim][{ce}], one launch per chunk (rmav_rollout_chunked)" if chunk_major else "") +
                        ("; per-env mass, load mass and tether length (3 x 4 B per env and launch read, constants re-derived per lane)" if per_env_params else ""),
            "launches": K, "warmup": W, "value": n * chunk * K / wall, "unit": "env-steps/s", "ms_per_launch_wall": 1e3 * wall / K,
            "finished_episodes": fin,
@@ -598,6 +605,8 @@ def main():
             try:   # the other single-GPU BASELINE configs, each a short leg with its own roofline object
                 if "c3_shard" in sec and n != 131072:
                     other["c3_shard"] = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 600, 150, "BASELINE configs[2]'s per-GPU shard")
+                    other["c3_shard_chunked"] = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 600, 150,
+                                                            "BASELINE configs[2]'s per-GPU shard, chunk-major trajectories", chunk_major=True)
                 if "c4" in sec:
                     other["c4"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80, "BASELINE configs[3] (C4)",
                                               cpu_seconds=min(3.0, args.cpu_seconds))
@@ -671,6 +680,13 @@ def main():
                                "value": 131072 * world * args.chunk / (float(tmax[0]) * 1e-3), "unit": "env-steps/s",
                                "roofline_frac_slowest_rank": leg["roofline"]["bytes_per_launch"] / (float(tmax[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "is_baseline_config_2": world == 8}
+                # the same shard with chunk-major trajectory arrays (rmav_rollout_chunked: one 65 536-env launch per chunk)
+                leg2 = rollout_leg(g, torch, dev, "quad3d", 131072, args.chunk, 300, 80, f"BASELINE configs[2]'s shard on each of {world} ranks, chunk-major",
+                                   env_id_base=rank * 131072, before_timed=dist.barrier, chunk_major=True)
+                t2 = torch.tensor([leg2["ms_per_launch_wall"], leg2["roofline"]["launch_ms_hip_events"]], dtype=torch.float64, device="cpu" if gloo else dev)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                other["c3"]["chunk_major"] = {"value": 131072 * world * args.chunk / (float(t2[0]) * 1e-3), "launch_ms_hip_events_max_over_ranks": float(t2[1]),
+                                              "roofline_frac_slowest_rank": leg2["roofline"]["bytes_per_launch"] / (float(t2[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS}
             except Exception as e:  # pragma: no cover
                 other["c3_error"] = repr(e)
         if gathered is not None:
@@ -828,6 +844,8 @@ def main():
             elif "roofline_frac_slowest_rank" in v:
                 row["frac"] = round(v["roofline_frac_slowest_rank"], 4)
                 row["envs_total"] = v.get("envs_total")
+                if "chunk_major" in v:
+                    row["chunk_major"] = {"value": float(f"{v['chunk_major']['value']:.4g}"), "frac": round(v["chunk_major"]["roofline_frac_slowest_rank"], 4)}
             if k == "policy_rollout":
                 row = {a: {"value": float(f"{x['kernel_env_steps_per_s']:.4g}"), "bound": x["bound"], "frac": round(x["bound_frac"], 3)}
                        for a, x in v.items() if isinstance(x, dict) and "bound" in x}

@@ -29,7 +29,7 @@
  *   the test loop "control -> step -> reset on done"              rmav_rollout(RMAV_ACT_CONTROLLER)
  *                                   test/test_quadrotor3d.py:16-22
  *   baselines VecEnv rollouts driven by gym_reinmav/run.py:89,190-211
- *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM)
+ *                                                                 rmav_rollout(RMAV_ACT_BUFFER|RANDOM), rmav_rollout_chunked
  *   baselines ppo2 Runner.run(): model.step(obs) + env.step(a)    rmav_rollout_policy (+ rmav_pack_policy)
  *   baselines Monitor episode statistics (info['episode'])        rmav_episode_totals / _buffers
  *   baselines ppo2 Runner.run() advantage pass (GAE lambda)       rmav_gae, rmav_normalize
@@ -268,6 +268,23 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
 int64_t rmav_trajectory_pitch(rmav_handle h);
 int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
                          float *obs_out, float *rew_out, uint8_t *done_out, int64_t pitch, int fused);
+
+/* rmav_rollout (fused) with CHUNK-MAJOR trajectory arrays: the env range is cut into chunks of chunk_envs (a multiple of 64; the last
+ * one may be shorter) and chunk c's trajectory is a dense array of its own,
+ *   actions_in / actions_out [n_chunks][n_steps][nA][chunk_envs], obs_out [n_chunks][n_steps][nS][chunk_envs], rew_out / done_out
+ *   [n_chunks][n_steps][chunk_envs]    (env i = chunk i / chunk_envs, column i % chunk_envs; device pointers; same values as rmav_rollout).
+ * Why: the fused rollout of quadrotor3d is bound by its trajectory stores, and a launch over 65 536 envs writing ONE dense region is what
+ * the store stream of this GPU likes best; slicing a big batch into such launches does not help as long as every launch writes a strided
+ * half / quarter of arrays laid out for the whole batch (a 65 536-env launch into arrays of pitch 131 072: 53 us instead of 40 - 42), with
+ * chunk-major arrays it does.  Measured (profiles/r05/chunk_probe.md, one box, 64-step launches): quadrotor3d random actions 131 072 envs
+ * 91.2 -> 87.1 us (0.72 -> 0.75 of the 8 TB/s roofline), 262 144 envs 190.2 -> 175.2 (0.69 -> 0.75), 1 048 576 unchanged; the slung-load
+ * kinds, controller-driven rollouts and the 2-D kinds are 3 - 10 % SLOWER chunked (their launches are not store-bound), so
+ * rmav_chunk_envs() recommends a chunk only for quadrotor3d beyond 65 536 envs and returns N (one chunk = the plain layout) otherwise.
+ * A learner that flattens (step, env) samples anyway - PPO2 does - consumes the chunks as they are.
+ * n_steps >= 2; chunk_envs a multiple of 64, at most the two-wavefront kernel's capacity (131 072; 65 536 for controller-driven slung-load). */
+int64_t rmav_chunk_envs(rmav_handle h);
+int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
+                         float *obs_out, float *rew_out, uint8_t *done_out, int64_t chunk_envs);
 
 /* PPO2-style rollout with the policy inside the kernel (the caller loop of gym_reinmav/run.py:63-68:
  * baselines ppo2 Runner = model.step(obs) -> env.step(actions), network='mlp').  Policy: two 64-unit tanh

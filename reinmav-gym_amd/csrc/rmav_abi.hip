@@ -213,6 +213,10 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
 bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, bool random_actions) {
     const int forced = h->tune[RMAV_TUNE_SPLIT], slice_forced = h->tune[RMAV_TUNE_SLICE];
     *slices = 1;
+    if (h->chunk > 0) {   // rmav_rollout_chunked: one two-wavefront launch per chunk, whatever the other rules say
+        *slices = (int)((h->n + h->chunk - 1) / h->chunk);
+        return true;
+    }
     // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
     const int min_steps = h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] > 0 ? h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] : 2;
     if (a.n_steps < min_steps || h->kind > RMAV_QUAD3D_SL) return false;
@@ -248,12 +252,25 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
             if (use_split(h, a, MODE != ACT_CONTROLLER, &slices, MODE == ACT_RANDOM)) {
                 const int st = pick_store_policy(h, a, true);
                 // balanced slices, each a multiple of 64 envs
-                const int64_t per = slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;
+                const int64_t per = h->chunk > 0 ? h->chunk : slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;
                 for (int64_t first = 0; first < h->n; first += per) {
                     RolloutArgs b = a;
-                    if (slices > 1) {
+                    if (slices > 1 || h->chunk > 0) {
                         b.slice_first = (uint32_t)first;
                         b.slice_count = (uint32_t)((h->n - first < per) ? h->n - first : per);
+                    }
+                    if (h->chunk > 0) {
+                        // chunk-major trajectory arrays [n_chunks][T][dim][chunk]: this launch's chunk is a dense region of its own with
+                        // column pitch `chunk`; the kernels index columns by the env's index in the handle, so the base pointers are moved
+                        // back by `first` columns (a multiple of 64 elements: alignment is kept)
+                        const int64_t c = first / per, T = a.n_steps;
+                        constexpr int64_t NS = Dims<K>::NS, NA = Dims<K>::NA;
+                        b.pitch = per;
+                        if (a.act_in) b.act_in = a.act_in + c * T * NA * per - first;
+                        if (a.act_out) b.act_out = a.act_out + c * T * NA * per - first;
+                        if (a.obs_out) b.obs_out = a.obs_out + c * T * NS * per - first;
+                        if (a.rew_out) b.rew_out = a.rew_out + c * T * per - first;
+                        if (a.done_out) b.done_out = a.done_out + c * T * per - first;
                     }
                     int rc;
                     switch (st) {
@@ -941,6 +958,31 @@ int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const 
     if (pitch <= 0) return rmav_fail(RMAV_ERR_INVALID, "pitch must be > 0 (rmav_trajectory_pitch)");
     return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE,
                         RMAV_SOA, fused, pitch);
+}
+
+// Chunk-major trajectories: see include/rmav.h.  The recommended chunk is the batch the two-wavefront kernel runs best at for the
+// kind whose launches are bound by the trajectory stores (65 536 envs = one (integrator, memory) pair per SIMD): profiles/r05/chunk_probe.md.
+int64_t rmav_chunk_envs(rmav_handle h) {
+    if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid handle");
+    // measured: quadrotor3d with random / caller actions gains 5 - 9 % at 131 072 - 262 144 envs; every other kind loses 3 - 10 %
+    return (h->kind == RMAV_QUAD3D && h->n > 65536) ? 65536 : h->n;
+}
+
+int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
+                         float *obs_out, float *rew_out, uint8_t *done_out, int64_t chunk_envs) {
+    CHECK_HANDLE(h);
+    if (chunk_envs <= 0 || (chunk_envs & 63)) return rmav_fail(RMAV_ERR_INVALID, "chunk_envs must be a positive multiple of 64 (rmav_chunk_envs)");
+    if (chunk_envs >= h->n)   // one chunk: the plain feature-major layout
+        return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE, RMAV_SOA, 1,
+                            chunk_envs > h->n ? chunk_envs : 0);
+    if (h->kind > RMAV_QUAD3D_SL) return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts are for the quadrotor kinds");
+    const int64_t cap = kEnvsPerCuSlot * (action_mode == RMAV_ACT_CONTROLLER ? kSplitPairsController : kSplitPairsRandom)[h->kind];
+    if (n_steps < 2 || chunk_envs > cap)
+        return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts need n_steps >= 2 and chunk_envs <= %lld for this kind and action source", (long long)cap);
+    h->chunk = chunk_envs;
+    const int rc = rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE, RMAV_SOA, 1);
+    h->chunk = 0;
+    return rc;
 }
 
 int rmav_step_control(rmav_handle h, const float *actions, float *obs_out, float *rew_out, uint8_t *done_out,

@@ -44,6 +44,7 @@ struct rmav_env_s {
     hipStream_t stream;
     bool own_stream;
     uint64_t t;  // global step counter
+    int64_t chunk;  // > 0 only inside rmav_rollout_chunked: the call's trajectory arrays are chunk-major [n_chunks][T][dim][chunk]
     // device-resident env data
     float *state;
     int32_t *sbd;

@@ -95,6 +95,8 @@ PROTOTYPES = {
                                C.c_int]),
     "rmav_trajectory_pitch": (C.c_int64, [C.c_void_p]),
     "rmav_rollout_pitched": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int64, C.c_int]),
+    "rmav_chunk_envs": (C.c_int64, [C.c_void_p]),
+    "rmav_rollout_chunked": (C.c_int, [C.c_void_p, C.c_int32, C.c_int, _fp, _fp, _fp, _fp, _u8p, C.c_int64]),
     "rmav_policy_weight_count": (C.c_int64, [C.c_int]),
     "rmav_policy_weight_count_bf16": (C.c_int64, []),
     "rmav_policy_weight_count_f32_mfma": (C.c_int64, []),

@@ -307,6 +307,45 @@ class BatchedQuadrotor:
             res["actions"] = a_in
         return res
 
+    def rollout_chunked(self, n_steps: int, mode: str = "random", actions=None, chunk: Optional[int] = None,
+                        want=("obs", "rew", "done"), out: Optional[dict] = None) -> dict:
+        """Fused rollout with CHUNK-MAJOR device trajectories (``rmav_rollout_chunked``): 'actions' ``[C, T, nA, chunk]``, 'obs'
+        ``[C, T, nS, chunk]``, 'rew' / 'done' ``[C, T, chunk]`` with ``C = ceil(N / chunk)``; env ``i`` is column ``i % chunk`` of chunk
+        ``i // chunk`` (columns past N in the last chunk are never written).  Same values as :meth:`rollout`; for big batches of the
+        3-D kinds each chunk runs as its own launch at the 65 536-env rate (include/rmav.h says why).  ``chunk`` defaults to
+        ``rmav_chunk_envs()``.  :meth:`unchunk` gives the plain ``[T, dim, N]`` view of a result (a copy)."""
+        T, m = int(n_steps), _MODES[mode]
+        ch = int(self._lib.rmav_chunk_envs(self._h)) if chunk is None else int(chunk)
+        if ch <= 0:
+            A.check(ch)
+        ch = min(ch, (self.num_envs + 63) // 64 * 64)
+        nc = -(-self.num_envs // ch)
+        shapes = {"actions": (nc, T, self.nA, ch), "obs": (nc, T, self.nS, ch), "rew": (nc, T, ch), "done": (nc, T, ch)}
+        a_in = None
+        if m == A.ACT_BUFFER:
+            a_in, _ = self._in(actions, shapes["actions"])
+        res = dict(out) if out else {}
+        for key in want:
+            if key == "actions" and m == A.ACT_BUFFER:
+                continue
+            if key not in res:
+                res[key] = self._new(shapes[key], np.uint8 if key == "done" else np.float32, True)
+            elif tuple(res[key].shape) != shapes[key] or not res[key].is_contiguous():
+                raise ValueError(f"out[{key!r}]: expected a contiguous tensor of shape {shapes[key]}")
+        A.check(self._lib.rmav_rollout_chunked(self._h, T, m, self._ptr(a_in), self._ptr(res.get("actions")) if m != A.ACT_BUFFER else None,
+                                               self._ptr(res.get("obs")), self._ptr(res.get("rew")), self._ptr(res.get("done")), ch))
+        if m == A.ACT_BUFFER and "actions" in want:
+            res["actions"] = a_in
+        return res
+
+    def unchunk(self, x):
+        """``[C, T, dim, chunk]`` / ``[C, T, chunk]`` -> ``[T, dim, N]`` / ``[T, N]`` (a copy, for code that wants the plain layout)."""
+        if x.dim() == 4:
+            c, t, d, ch = x.shape
+            return x.permute(1, 2, 0, 3).reshape(t, d, c * ch)[..., :self.num_envs].contiguous()
+        c, t, ch = x.shape
+        return x.permute(1, 0, 2).reshape(t, c * ch)[..., :self.num_envs].contiguous()
+
     # ---- state access ----------------------------------------------------------------------------------
     def get_state(self, layout: str = "aos", device_out: bool = False):
         s = self._new(self._shape(self.nS, layout), np.float32, device_out)

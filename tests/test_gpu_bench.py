@@ -88,7 +88,8 @@ def test_bench_single_process_line(built):
     assert 0.0 < om["rollout_in_place"]["roofline_frac"] <= 1.0
     st = om["step"]["roofline"]                                  # the per-step path carries its own roofline object
     assert 0.0 < st["frac"] <= 1.0 and st["bytes_per_launch"] == 65536 * 101 and st["bound"] == "hbm"
-    for leg, kind_n in (("c3_shard", 131072 * (64 * 61 + 104)), ("c4", 262144 * (64 * 85 + 152))):   # the other single-GPU configs
+    for leg, kind_n in (("c3_shard", 131072 * (64 * 61 + 104)), ("c3_shard_chunked", 131072 * (64 * 61 + 104)),
+                        ("c4", 262144 * (64 * 85 + 152))):   # the other single-GPU configs
         lr = om[leg]["roofline"]
         assert lr["bytes_per_launch"] == kind_n and 0.0 < lr["frac"] <= 1.0, (leg, lr)
         assert om[leg]["finished_episodes"] > 0

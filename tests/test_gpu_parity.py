@@ -756,6 +756,76 @@ def test_pitched_rollout_equals_the_plain_layout(G, kind, n, T, fused, mode):
     ref_env.close()
 
 
+@pytest.mark.parametrize("mode", ["random", "controller", "buffer"])
+@pytest.mark.parametrize("kind,n,chunk,T", [("quad3d", 131072, 65536, 12), ("quad3d", 150016, 65536, 9), ("quad3d_sl", 70000, 32768, 10),
+                                            ("quad2d", 20000, 8192, 16), ("quad2d_sl", 4099, 1024, 7), ("quad3d", 5000, 8192, 6)])
+def test_chunked_rollout_equals_the_plain_layout(G, kind, n, chunk, T, mode):
+    """rmav_rollout_chunked (chunk-major trajectory arrays [C][T][dim][chunk], one two-wavefront launch per chunk) writes the values
+    rmav_rollout writes - permuted, nothing else - leaves columns past N in the last chunk alone, and leaves the envs in the same
+    state with the same counters and episode statistics.  Ragged last chunks, a chunk larger than the batch (= the plain layout
+    with a pitch), caller actions in the chunked layout."""
+    import torch
+
+    nS, nA = NS[kind], NA[kind]
+    lo, hi = BOX[kind]
+    want = ("actions", "obs", "rew", "done")
+    acts = None
+    if mode == "buffer":
+        acts = torch.empty((T, nA, n), device="cuda").uniform_(lo, hi, generator=torch.Generator(device="cuda").manual_seed(5))
+    ref_env = G.BatchedQuadrotor(kind, n, seed=21, auto_reset=True, track_episodes=True)
+    ref = ref_env.rollout(T, mode=mode, actions=acts, layout="soa", want=want, device_out=True)
+    env = G.BatchedQuadrotor(kind, n, seed=21, auto_reset=True, track_episodes=True)
+    ch = min(chunk, (n + 63) // 64 * 64)
+    nc = -(-n // ch)
+    SENT = -4321.0
+    out = {"obs": torch.full((nc, T, nS, ch), SENT, device="cuda"), "rew": torch.full((nc, T, ch), SENT, device="cuda"),
+           "done": torch.full((nc, T, ch), 55, dtype=torch.uint8, device="cuda")}
+    a_chunked = None
+    if mode == "buffer":
+        pad = torch.zeros((T, nA, nc * ch), device="cuda")
+        pad[..., :n] = acts
+        a_chunked = pad.reshape(T, nA, nc, ch).permute(2, 0, 1, 3).contiguous()
+    else:
+        out["actions"] = torch.full((nc, T, nA, ch), SENT, device="cuda")
+    tr = env.rollout_chunked(T, mode=mode, actions=a_chunked, chunk=chunk, want=want, out=out)
+    torch.cuda.synchronize()
+    for k in want:
+        assert torch.equal(env.unchunk(tr[k]), ref[k]), k
+    tail = nc * ch - n                                   # columns of the last chunk that belong to no env: untouched
+    if tail:
+        assert bool((out["obs"][-1, :, :, ch - tail:] == SENT).all()) and bool((out["rew"][-1, :, ch - tail:] == SENT).all())
+        assert bool((out["done"][-1, :, ch - tail:] == 55).all())
+    assert np.array_equal(env.get_state(), ref_env.get_state()) and np.array_equal(env.get_reset_counts(), ref_env.get_reset_counts())
+    assert np.array_equal(env.get_sbd(), ref_env.get_sbd())
+    ea, eb = env.episode_buffers(), ref_env.episode_buffers()
+    assert all(np.array_equal(ea[k], eb[k]) for k in ea)
+    ta, tb = env.episode_totals(), ref_env.episode_totals()
+    assert ta["episodes"] == tb["episodes"] and ta["length_sum"] == tb["length_sum"]
+    # a second call continues from there (step counter, RNG blocks) exactly like the plain one
+    tr2 = env.rollout_chunked(T, mode=("random" if mode == "buffer" else mode), chunk=chunk, want=("obs", "done"))
+    ref2 = ref_env.rollout(T, mode=("random" if mode == "buffer" else mode), layout="soa", want=("obs", "done"), device_out=True)
+    assert torch.equal(env.unchunk(tr2["obs"]), ref2["obs"]) and torch.equal(env.unchunk(tr2["done"]), ref2["done"])
+    env.close()
+    ref_env.close()
+
+
+def test_chunked_rollout_rejects_bad_arguments(G):
+    from gym_reinmav_amd import _abi as A
+
+    env = G.BatchedQuadrotor("quad3d", 200000, seed=1)
+    assert int(env._lib.rmav_chunk_envs(env._h)) == 65536
+    with pytest.raises(A.RmavError):
+        env.rollout_chunked(8, chunk=1000)            # not a multiple of 64
+    with pytest.raises(A.RmavError):
+        env.rollout_chunked(1, chunk=65536)           # n_steps >= 2
+    with pytest.raises(A.RmavError):
+        env.rollout_chunked(8, chunk=196608)          # beyond the two-wavefront kernel's capacity
+    env.close()
+    small = G.BatchedQuadrotor("quad2d", 200000, seed=1)
+    assert int(small._lib.rmav_chunk_envs(small._h)) == 200000   # only quadrotor3d's launches are store-bound: one chunk = the plain layout
+    small.close()
+
+
 def test_pitched_rollout_rejects_bad_arguments(G):
     import torch
     from gym_reinmav_amd import _abi as A

@@ -245,3 +245,4 @@ def test_bench_multi_gpu_line_carries_the_c3_leg(stub):
     c3 = json.load(open(os.path.join(ROOT, j["detail"])))["other_modes"]["c3"]   # ... the full leg in the detail file
     assert c3["envs_total"] == 2 * 131072 and c3["value"] > 0 and 0.0 < c3["roofline_frac_slowest_rank"] <= 1.0
     assert c3["is_baseline_config_2"] is False
+    assert c3["chunk_major"]["value"] > 0 and 0.0 < row["chunk_major"]["frac"] <= 1.0      # ... and with chunk-major trajectory arrays
