@@ -147,10 +147,24 @@ class NativeQuadrotorEnv(_EnvBase):
         self._batch.params = p          # rmav_set_params validates (raises RmavError on e.g. mass <= 0)
         self._ctrl_valid = False
 
-    def _vec(self, values, setter):
-        a = _WriteThrough(np.asarray(values, dtype=np.float64))
-        a._on_write = setter
+    def _vec(self, read, setter):
+        """A snapshot of a vector-valued constant whose ELEMENT writes go through: `a[key] = value` applies that one assignment to
+        the handle's CURRENT value (not to the snapshot's other, possibly stale, elements) and refreshes the snapshot."""
+        a = _WriteThrough(read())
+
+        def on_write(key, value):
+            cur = np.array(read(), dtype=np.float64)
+            cur[key] = value
+            setter(cur)
+            np.ndarray.__setitem__(a, slice(None), read())
+        a._on_write = on_write
         return a
+
+    def _read_vec(self, name):
+        return np.array(list(getattr(self._batch.params, name))[:self._dim], dtype=np.float64)
+
+    def _read_g(self):
+        return np.array([0.0] * (self._dim - 1) + [-self._batch.params.g])
 
     mass = property(lambda self: self._batch.params.mass, lambda self, v: self._set_param(mass=v))
     dt = property(lambda self: self._batch.params.dt, lambda self, v: self._set_param(dt=v))
@@ -177,8 +191,7 @@ class NativeQuadrotorEnv(_EnvBase):
     @property
     def g(self):
         """Gravity vector (0, [0,] -g) like quadrotor3d.py:47; only its vertical component can be non-zero here."""
-        v = [0.0] * (self._dim - 1) + [-self._batch.params.g]
-        return self._vec(v, self._set_g)
+        return self._vec(self._read_g, self._set_g)
 
     @g.setter
     def g(self, v):
@@ -192,7 +205,7 @@ class NativeQuadrotorEnv(_EnvBase):
 
     @property
     def ref_pos(self):
-        return self._vec(list(self._batch.params.ref_pos)[:self._dim], lambda v: self._set_param(ref_pos=v))
+        return self._vec(lambda: self._read_vec("ref_pos"), lambda v: self._set_param(ref_pos=v))
 
     @ref_pos.setter
     def ref_pos(self, v):
@@ -200,7 +213,7 @@ class NativeQuadrotorEnv(_EnvBase):
 
     @property
     def ref_vel(self):
-        return self._vec(list(self._batch.params.ref_vel)[:self._dim], lambda v: self._set_param(ref_vel=v))
+        return self._vec(lambda: self._read_vec("ref_vel"), lambda v: self._set_param(ref_vel=v))
 
     @ref_vel.setter
     def ref_vel(self, v):
@@ -221,9 +234,10 @@ class _WriteThrough(np.ndarray):
         self._on_write = None           # views / results of arithmetic do not write through
 
     def __setitem__(self, key, value):
-        np.ndarray.__setitem__(self, key, value)
         if self._on_write is not None:
-            self._on_write(np.asarray(self))
+            self._on_write(key, value)      # validates, writes the handle, refreshes this snapshot
+        else:
+            np.ndarray.__setitem__(self, key, value)
 
     def __array_wrap__(self, out, context=None, return_scalar=False):
         out = np.asarray(out)

@@ -139,6 +139,12 @@ def test_gym_env_public_attributes_write_through(G):
     exp2 = O.control("quad3d", obs, p)
     assert np.abs(a2 - cached).max() > 1e-3
     ctrl_close(a2, exp2)
+    old = env.ref_pos                                   # a snapshot kept across a re-assignment ...
+    env.ref_pos = (1.0, 0.5, 2.5)
+    p.ref_pos[1] = 0.5
+    old[0] = 1.25                                       # ... writes ONE element of the CURRENT value, not its stale other elements
+    p.ref_pos[0] = 1.25
+    assert list(env.ref_pos) == [1.25, 0.5, 2.5] and list(old) == [1.25, 0.5, 2.5]
     env.ref_vel = [0.1, 0.0, -0.1]
     env.dt = 0.02
     env.g = np.array([0.0, 0.0, -3.7])
