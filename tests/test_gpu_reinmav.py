@@ -140,3 +140,19 @@ def test_rk4_option_vs_oracle_and_vs_euler(G, gold):
     with pytest.raises(G.RmavError):
         G.BatchedQuadrotor("reinmav", 4, params=bad)
     env.close()
+
+
+def test_trj_gen_is_the_reference_min_jerk_profile(G):
+    """ReinmavEnv.trj_gen (reinmav_env.py:128-136): the quintic in s = clip(t, 0, 4) / 4 and its two derivatives, the same profile on
+    x, y, z and yaw - [x, y, z, vx, vy, vz, ax, ay, az, yaw, yaw rate].  Closed-form spot values + the clipping at both ends."""
+    env = G.make("reinmav-v0")
+    d = env.trj_gen(2.0)                       # s = 1/2: pos 1/2, vel 15/32, acc 0
+    assert len(d) == 11 and d[0] == d[1] == d[2] == d[9] == 0.5
+    assert abs(d[3] - 0.46875) < 1e-15 and d[3] == d[4] == d[5] == d[10] and abs(d[6]) < 1e-15 and d[6] == d[7] == d[8]
+    assert env.trj_gen(-1.0) == [0.0] * 11 and env.trj_gen(0.0) == [0.0] * 11
+    end = env.trj_gen(9.0)
+    assert end[0] == 1.0 and abs(end[3]) < 1e-15 and abs(end[6]) < 1e-13 and end == env.trj_gen(4.0)
+    s = 0.3 / 4.0
+    assert abs(env.trj_gen(0.3)[0] - (10 * s ** 3 - 15 * s ** 4 + 6 * s ** 5)) < 1e-16
+    assert abs(env.trj_gen(0.3)[6] - (60 / 16 * s - 180 / 16 * s ** 2 + 120 / 16 * s ** 3)) < 1e-15
+    env.close()
