@@ -1313,10 +1313,17 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     const bool track = (a.flags & F_TRACK) != 0;
     const bool auto_reset = (a.flags & F_AUTO_RESET) != 0;
 
-    // this wavefront's totals slot, through the scalar cache (wave-uniform address)
+    // This wavefront's slot of the episode totals is read at the top of the kernel and rewritten by one lane at the end (no atomics).
+    // Through the scalar cache the read shares lgkmcnt with the late kernel-argument loads, so the `s_waitcnt lgkmcnt(0)` in front of
+    // the bookkeeping loads also waits for that memory round trip; as a VECTOR load issued behind all other loads it does not.
+    // Same-box A/B (profiles/r05/step_totals_ab.md): the vector form is 2.5 - 6 % faster for the 3-D kinds up to 262 144 envs (65 536:
+    // 4.32 - 4.47 -> 4.18 - 4.24 us) and 1 - 3.5 % slower for the 2-D kinds and the lazy kernel of the big batches - so it is chosen by kind.
+    constexpr bool kVectorTotals = !LAZY && (K == QUAD3D || K == QUAD3D_SL);
     const uint32_t wave = __builtin_amdgcn_readfirstlane(gi >> 6);
     Totals tot = {0ull, 0.0, 0ull};
-    if (track) tot = a.totals[wave];
+    if constexpr (!kVectorTotals) {
+        if (track) tot = a.totals[wave];
+    }
 
     const rsrc_t r_state = make_rsrc(a.state);
     float s[NS], act[NA];
@@ -1353,6 +1360,11 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
         rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
         if (track) es = (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0);
+    }
+    if constexpr (kVectorTotals) if (track) {
+        const Totals *tp = a.totals + (gi >> 6);
+        asm volatile("" : "+v"(tp));          // keep it a vector address (vmcnt, in order), not an s_load
+        tot = *tp;
     }
     typename Env<K>::P pl = p_shared;
     ParamsT<double> pcl = pc_shared;
