@@ -353,6 +353,54 @@ def step_leg(g, torch, dev, kind: str, n: int, K: int, W: int, tune=None):
                                                            "(tools/micro/launch_floor.hip): a bound on any one-launch-per-step kernel at small batches"})}
 
 
+def leg_rows(other: dict) -> dict:
+    """One short row per secondary leg for the compact line (the full objects go to the detail file)."""
+    legs = {}
+    for k, v in other.items():
+        if not isinstance(v, dict):
+            legs[k] = str(v)[:120]
+            continue
+        row = {}
+        if "value" in v:
+            row["value"] = float(f"{v['value']:.4g}")
+        r_ = v.get("roofline")
+        if isinstance(r_, dict) and "frac" in r_:
+            row["frac"] = round(r_["frac"], 4)
+            row["bound"] = r_.get("bound", "hbm")
+            ms_ = r_.get("launch_ms_hip_events", v.get("ms_per_launch_hip_events"))
+            if ms_:
+                row["us"] = round(1e3 * ms_, 3)
+            if r_.get("traffic_over_needed"):
+                row["traffic_over_needed"] = round(r_["traffic_over_needed"], 3)
+        elif "roofline_frac" in v:
+            row["frac"] = round(v["roofline_frac"], 4)
+            row["us"] = round(1e3 * v.get("ms_per_launch_hip_events", 0.0), 3)
+        elif "roofline_frac_slowest_rank" in v:
+            row["frac"] = round(v["roofline_frac_slowest_rank"], 4)
+            row["envs_total"] = v.get("envs_total")
+            if "chunk_major" in v:
+                row["chunk_major"] = {"value": float(f"{v['chunk_major']['value']:.4g}"), "frac": round(v["chunk_major"]["roofline_frac_slowest_rank"], 4)}
+        if k == "policy_rollout":
+            row = {a: {"value": float(f"{x['kernel_env_steps_per_s']:.4g}"), "bound": x["bound"], "frac": round(x["bound_frac"], 3)}
+                   for a, x in v.items() if isinstance(x, dict) and "bound" in x}
+        if k == "gym1":
+            row = {"us_control_plus_step": round(v["us_per_iteration_control_plus_step"], 2), "reference_us_per_step": v["reference_us_per_step"]}
+        if k == "vecenv":
+            row = {kk: round(vv["us_per_step"], 2) for kk, vv in v.items() if isinstance(vv, dict)}
+        legs[k] = row
+    return legs
+
+
+def compact_text(line: dict) -> str:
+    """The final stdout line: < 4 KB whatever the legs (the driver keeps an 8 KB tail; round 4's 22 KB line was lost to it) - optional
+    rows are dropped before that could happen."""
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) > 4000:
+        line = {k: v for k, v in line.items() if k not in ("legs", "cpu_mt")}
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -820,40 +868,7 @@ def main():
                                                                "env-steps/s in the authoring container, BASELINE.md section 2)"}
                 except Exception as e:  # pragma: no cover
                     detail["cpu_baseline_python"] = {"error": repr(e)}
-        # one short row per secondary leg (the full objects are in the detail file)
-        legs = {}
-        for k, v in other.items():
-            if not isinstance(v, dict):
-                legs[k] = str(v)[:120]
-                continue
-            row = {}
-            if "value" in v:
-                row["value"] = float(f"{v['value']:.4g}")
-            r_ = v.get("roofline")
-            if isinstance(r_, dict) and "frac" in r_:
-                row["frac"] = round(r_["frac"], 4)
-                row["bound"] = r_.get("bound", "hbm")
-                ms_ = r_.get("launch_ms_hip_events", v.get("ms_per_launch_hip_events"))
-                if ms_:
-                    row["us"] = round(1e3 * ms_, 3)
-                if r_.get("traffic_over_needed"):
-                    row["traffic_over_needed"] = round(r_["traffic_over_needed"], 3)
-            elif "roofline_frac" in v:
-                row["frac"] = round(v["roofline_frac"], 4)
-                row["us"] = round(1e3 * v.get("ms_per_launch_hip_events", 0.0), 3)
-            elif "roofline_frac_slowest_rank" in v:
-                row["frac"] = round(v["roofline_frac_slowest_rank"], 4)
-                row["envs_total"] = v.get("envs_total")
-                if "chunk_major" in v:
-                    row["chunk_major"] = {"value": float(f"{v['chunk_major']['value']:.4g}"), "frac": round(v["chunk_major"]["roofline_frac_slowest_rank"], 4)}
-            if k == "policy_rollout":
-                row = {a: {"value": float(f"{x['kernel_env_steps_per_s']:.4g}"), "bound": x["bound"], "frac": round(x["bound_frac"], 3)}
-                       for a, x in v.items() if isinstance(x, dict) and "bound" in x}
-            if k == "gym1":
-                row = {"us_control_plus_step": round(v["us_per_iteration_control_plus_step"], 2), "reference_us_per_step": v["reference_us_per_step"]}
-            if k == "vecenv":
-                row = {kk: round(vv["us_per_step"], 2) for kk, vv in v.items() if isinstance(vv, dict)}
-            legs[k] = row
+        legs = leg_rows(other)
         if legs:
             line["legs"] = legs
         dpath = args.detail
@@ -867,11 +882,7 @@ def main():
                 line["detail"] = os.path.relpath(dpath, ROOT) if os.path.abspath(dpath).startswith(ROOT) else dpath
             except Exception as e:  # pragma: no cover - the line matters more than the file
                 line["detail"] = "not written: " + repr(e)[:80]
-        text = json.dumps(line, separators=(",", ":"))
-        if len(text) > 4000:   # never again a line the driver cannot recover: drop the optional rows first
-            for k in ("legs", "cpu_mt"):
-                line.pop(k, None)
-            text = json.dumps(line, separators=(",", ":"))
+        text = compact_text(line)
         sys.stdout.flush()
         print(text, flush=True)
     if native_abandoned:   # a thread of this process is still inside RCCL: do not wait for it in any destructor
