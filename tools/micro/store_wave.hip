@@ -57,6 +57,25 @@ template <int G> __global__ __launch_bounds__(64) void k_cu(float *arena, uint32
     }
 }
 
+// one wavefront per 64 envs, but the G = 4 wavefronts of a 256-thread workgroup share the rows: wavefront m stores rows m, m + 4, ... for all
+// 256 envs of the workgroup with 1 KiB-wide dwordx4 stores (what a cooperative drain of the four pairs' hand-over tiles would issue)
+__global__ __launch_bounds__(256) void k_coop(float *arena, uint32_t n, int T, int work) {
+    const uint32_t first = blockIdx.x * 256u, lane = threadIdx.x & 63u, m = threadIdx.x >> 6;
+    if (first >= n) return;
+    float v = (float)(first + threadIdx.x);
+    const uint32_t col = n * 4u;
+    float *base = arena;
+    for (int t = 0; t < T; ++t) {
+        v = spin(v, work);
+        const rsrc_t r = rsrc(base);
+        const uint32_t b = __builtin_bit_cast(uint32_t, v);
+        const u32x4 q = {b, b + 1u, b + 2u, b + 3u};
+#pragma unroll
+        for (int c = 0; c < C / 4; ++c) __builtin_amdgcn_raw_buffer_store_b128(q, r, (first + 4u * lane) * 4u, (4u * c + m) * col, AUX);
+        base += (size_t)C * n;
+    }
+}
+
 template <typename F> double time_us(F launch, int reps) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -72,15 +91,16 @@ template <typename F> double time_us(F launch, int reps) {
 int main() {
     const int T = 64;
     printf("| envs | work per step | writers | us per launch | TB/s |\n|---|---|---|---|---|\n");
-    for (uint32_t n : {65536u, 131072u, 262144u, 524288u}) {
+    for (int rep = 0; rep < 2; ++rep) for (uint32_t n : {65536u, 131072u, 262144u}) {
         const size_t per = (size_t)T * C * n * 4;
         const int R = (int)((size_t(1600) << 20) / per) + 2;
         std::vector<float *> ring(R);
         for (auto &p : ring) { CK(hipMalloc(&p, per)); CK(hipMemset(p, 0, per)); }
         const int reps = (int)(65536ull * 300 / n) + 20;
-        for (int work : {0, 150, 300}) {
+        for (int work : {0}) {
             auto row = [&](const char *name, double us) { printf("| %u | %d | %s | %.1f | %.2f |\n", n, work, name, us, (double)per / us / 1e6); fflush(stdout); };
             row("pairs (1 per 64 envs)", time_us([&](int i) { hipLaunchKernelGGL(k_pairs, dim3((n + 255) / 256), dim3(256), 0, 0, ring[i % R], n, T, work); }, reps));
+            row("4 waves per 256 envs, rows shared, 1 KiB stores", time_us([&](int i) { hipLaunchKernelGGL(k_coop, dim3((n + 255) / 256), dim3(256), 0, 0, ring[i % R], n, T, work); }, reps));
             row("1 store wave per 256 envs", time_us([&](int i) { hipLaunchKernelGGL(k_cu<4>, dim3((n + 255) / 256), dim3(64), 0, 0, ring[i % R], n, T, work); }, reps));
             row("1 store wave per 512 envs", time_us([&](int i) { hipLaunchKernelGGL(k_cu<8>, dim3((n + 511) / 512), dim3(64), 0, 0, ring[i % R], n, T, work); }, reps));
             row("1 store wave per 1024 envs", time_us([&](int i) { hipLaunchKernelGGL(k_cu<16>, dim3((n + 1023) / 1024), dim3(64), 0, 0, ring[i % R], n, T, work); }, reps));
