@@ -78,7 +78,7 @@
 extern "C" {
 #endif
 
-#define RMAV_VERSION 100 /* 0.1.0 */
+#define RMAV_VERSION 101 /* 0.1.1: rmav_params.g_vec */
 
 typedef struct rmav_env_s *rmav_handle;
 
@@ -142,7 +142,8 @@ typedef struct rmav_params {
     double mass;          /* quadrotor3d.py:45 */
     double load_mass;     /* quadrotor3d_slungload.py:46 */
     double dt;            /* quadrotor3d.py:46 */
-    double g;             /* gravity magnitude; g = (0,-g) or (0,0,-g)  quadrotor3d.py:47 */
+    double g;             /* RMAV_REINMAV: the scalar self.gravity (reinmav_env.py:58).  Quadrotor kinds: not read (see g_vec);
+                             rmav_default_params fills 9.8 = |g_vec| for information */
     double tether_length; /* quadrotor3d_slungload.py:58 / quadrotor2d_slungload.py:53 */
     double pos_limit;     /* episode ends when |pos| > pos_limit (which body: see DESIGN.md) */
     double vel_limit;     /* ... or |vel| > vel_limit */
@@ -155,6 +156,9 @@ typedef struct rmav_params {
     double ref_vel[3];    /* quadrotor3d.py:52 */
     double kp, kv, tau;   /* controller gains  quadrotor3d.py:143-145, quadrotor2d.py:116-118 */
     double act_lo, act_hi; /* action Box bounds (quadrotor3d.py:70 etc.); used by RMAV_ACT_RANDOM only */
+    double g_vec[3];      /* quadrotor kinds: the gravity VECTOR self.g, added component-wise by step() and subtracted by the 3-D
+                             control() - quadrotor3d.py:47,96-99,162: (0, 0, -9.8); 2-D kinds use [0..1] - quadrotor2d.py:46,88:
+                             (0, -9.8) - and their control() keeps the reference's literal (0, 9.8) (quadrotor2d.py:130) */
 } rmav_params;
 
 typedef struct rmav_ep_totals {
@@ -279,7 +283,8 @@ int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const 
  * chunk-major arrays it does.  Measured (profiles/r05/chunk_probe.md, one box, 64-step launches): quadrotor3d random actions 131 072 envs
  * 91.2 -> 87.1 us (0.72 -> 0.75 of the 8 TB/s roofline), 262 144 envs 190.2 -> 175.2 (0.69 -> 0.75), 1 048 576 unchanged; the slung-load
  * kinds, controller-driven rollouts and the 2-D kinds are 3 - 10 % SLOWER chunked (their launches are not store-bound), so
- * rmav_chunk_envs() recommends a chunk only for quadrotor3d beyond 65 536 envs and returns N (one chunk = the plain layout) otherwise.
+ * rmav_chunk_envs() recommends a chunk only for quadrotor3d beyond 65 536 envs and returns N rounded up to a multiple of 64 (one chunk = the
+ * plain layout, with that column pitch when N % 64 != 0) otherwise.
  * A learner that flattens (step, env) samples anyway - PPO2 does - consumes the chunks as they are.
  * n_steps >= 2; chunk_envs a multiple of 64, at most the two-wavefront kernel's capacity (131 072; 65 536 for controller-driven slung-load). */
 int64_t rmav_chunk_envs(rmav_handle h);

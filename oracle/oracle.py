@@ -35,6 +35,7 @@ class Params(C.Structure):
         ("kp", C.c_double),
         ("kv", C.c_double),
         ("tau", C.c_double),
+        ("g_vec", C.c_double * 3),
     ]
 
 

@@ -21,7 +21,10 @@ Stand-ins (all our own code):
                      ``rotation_matrix`` (normalises ``self.q`` first when ``|1-|q|^2| >= 1e-14``),
                      ``derivative``, ``conjugate``, ``__mul__``/``__rmul__`` (Hamilton), ``elements``.
                      :func:`selfcheck_quaternion` cross-checks it against the independent
-                     ``scipy.spatial.transform.Rotation``.
+                     ``scipy.spatial.transform.Rotation`` (``rotation_matrix``, ``__mul__``, ``Quaternion(matrix=)``)
+                     and a component-wise Hamilton product (``derivative``).  When the REAL package is importable
+                     :func:`_install_stubs` uses it instead (``QUATERNION_SOURCE`` says which ran) and
+                     :func:`compare_with_real` checks stand-in == real member by member.
 * legacy NumPy     - the reference predates NumPy 1.24: it uses ``np.float``
                      (``quadrotor3d.py:70-71``) and builds ragged ``np.array((scalar, array([th]),...))``
                      (``quadrotor2d.py:113``).  ``_LegacyNumpy`` forwards everything to real NumPy and
@@ -185,27 +188,98 @@ class Quaternion:
         return self.q[1:4]
 
 
-def selfcheck_quaternion(n: int = 2000, seed: int = 7) -> tuple[float, float]:
-    """Cross-check the stand-in against scipy (independent implementation).
+def _hamilton(a, b):
+    """Hamilton product written out component by component (independent of the matrix form the stand-in uses)."""
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                     aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw])
 
-    Returns (max |R(q)e3 - scipy|, max |q1*q2 - scipy| up to sign)."""
+
+def selfcheck_quaternion(n: int = 2000, seed: int = 7, cls=None) -> tuple[float, float, float, float]:
+    """Cross-check a Quaternion class (default: the stand-in) against independent implementations, over the members the hot
+    path calls.
+
+    Returns (max |R(q)e3 - scipy|, max |q1*q2 - scipy| up to sign, max |Quaternion(matrix=R) - scipy from_matrix| up to sign,
+    max |q.derivative(w) - 0.5 q (x) (0, w)| against the component-wise Hamilton product)."""
     from scipy.spatial.transform import Rotation
 
+    Q = cls or Quaternion
     rng = np.random.RandomState(seed)
-    e_rot = 0.0
-    e_mul = 0.0
+    e_rot = e_mul = e_mat = e_der = 0.0
     for _ in range(n):
         q = rng.uniform(-1, 1, 4)
         p = rng.uniform(-1, 1, 4)
-        b3 = Quaternion(q).rotation_matrix.dot(np.array([0.0, 0.0, 1.0]))
+        b3 = Q(q).rotation_matrix.dot(np.array([0.0, 0.0, 1.0]))
         ref = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()[:, 2]
         e_rot = max(e_rot, float(np.abs(b3 - ref).max()))
         qu, pu = q / np.linalg.norm(q), p / np.linalg.norm(p)
-        prod = (Quaternion(qu) * Quaternion(pu)).elements
+        prod = (Q(qu) * Q(pu)).elements
         r = (Rotation.from_quat([qu[1], qu[2], qu[3], qu[0]]) * Rotation.from_quat([pu[1], pu[2], pu[3], pu[0]])).as_quat()
         r = np.array([r[3], r[0], r[1], r[2]])
         e_mul = max(e_mul, float(min(np.abs(prod - r).max(), np.abs(prod + r).max())))
-    return e_rot, e_mul
+        # Quaternion(matrix=) - the controller's acc2quat (quadrotor3d.py:139) - on a rotation matrix from an independent source
+        R = Rotation.from_quat([pu[1], pu[2], pu[3], pu[0]]).as_matrix()
+        qm = np.asarray(Q(matrix=R).elements, dtype=float)
+        r = Rotation.from_matrix(R).as_quat()
+        r = np.array([r[3], r[0], r[1], r[2]])
+        e_mat = max(e_mat, float(min(np.abs(qm - r).max(), np.abs(qm + r).max())))
+        # derivative (quadrotor3d.py:101) on the NON-unit q the env hands over after rotation_matrix normalised a copy
+        w = rng.uniform(-10, 10, 3)
+        d = np.asarray(Q(q).derivative(w).elements, dtype=float)
+        e_der = max(e_der, float(np.abs(d - 0.5 * _hamilton(q, np.array([0.0, w[0], w[1], w[2]]))).max()))
+    return e_rot, e_mul, e_mat, e_der
+
+
+def real_pyquaternion():
+    """The real ``pyquaternion`` package when it is importable (it is not in this image: requirements.txt:1 is un-vendored),
+    else None.  Never returns the stand-in module that :func:`_install_stubs` plants in ``sys.modules``."""
+    mod = sys.modules.get("pyquaternion")
+    if mod is not None:
+        return None if getattr(mod, "_rmav_stub", False) else mod
+    try:
+        import importlib
+
+        mod = importlib.import_module("pyquaternion")
+    except Exception:
+        return None
+    return mod
+
+
+# which Quaternion the loaded reference classes run on: "stand-in" or "pyquaternion <version>" (set by _install_stubs)
+QUATERNION_SOURCE = "stand-in"
+
+
+def compare_with_real(n: int = 2000, seed: int = 11) -> dict | None:
+    """Stand-in vs the REAL package on every member of row a10, when the package is importable (None otherwise):
+    max absolute difference per member.  tests/test_oracle_golden.py asserts <= 1e-15-ish on each."""
+    mod = real_pyquaternion()
+    if mod is None:
+        return None
+    from scipy.spatial.transform import Rotation
+
+    RQ = mod.Quaternion
+    rng = np.random.RandomState(seed)
+    out = {k: 0.0 for k in ("ctor", "rotation_matrix", "normalise_side_effect", "mul", "rmul", "derivative", "conjugate", "matrix")}
+
+    def upd(k, a, b):
+        out[k] = max(out[k], float(np.abs(np.asarray(a, dtype=float) - np.asarray(b, dtype=float)).max()))
+
+    for i in range(n):
+        q = rng.uniform(-1, 1, 4) * (1.0 if i % 2 else 3.0)
+        p = rng.uniform(-1, 1, 4)
+        w = rng.uniform(-10, 10, 3)
+        a, b = Quaternion(q), RQ(q)
+        upd("ctor", a.elements, b.elements)
+        upd("rotation_matrix", a.rotation_matrix, b.rotation_matrix)
+        upd("normalise_side_effect", a.elements, b.elements)          # rotation_matrix normalised self.q in place
+        upd("mul", (Quaternion(q) * Quaternion(p)).elements, (RQ(q) * RQ(p)).elements)
+        upd("rmul", (0.5 * Quaternion(q)).elements, (0.5 * RQ(q)).elements)
+        upd("derivative", Quaternion(q).derivative(w).elements, RQ(q).derivative(w).elements)
+        upd("conjugate", Quaternion(q).conjugate.elements, RQ(q).conjugate.elements)
+        R = Rotation.from_quat(p / np.linalg.norm(p)).as_matrix()
+        upd("matrix", Quaternion(matrix=R).elements, RQ(matrix=R).elements)
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -239,8 +313,16 @@ def _install_stubs() -> None:
     logger.warn = lambda msg, *a: WARNINGS.append(str(msg))
     utils.seeding = seeding
     gym.spaces, gym.error, gym.utils, gym.logger = spaces, error, utils, logger
-    pq = types.ModuleType("pyquaternion")
-    pq.Quaternion = Quaternion
+    # the REAL pyquaternion when the environment has it (RMAV_QUATERNION_STANDIN=1 forces the stand-in); the stand-in otherwise
+    global QUATERNION_SOURCE
+    pq = None if os.environ.get("RMAV_QUATERNION_STANDIN") == "1" else real_pyquaternion()
+    if pq is not None:
+        QUATERNION_SOURCE = "pyquaternion " + str(getattr(pq, "__version__", "?"))
+    else:
+        pq = types.ModuleType("pyquaternion")
+        pq._rmav_stub = True
+        pq.Quaternion = Quaternion
+        QUATERNION_SOURCE = "stand-in"
     sys.modules.update(
         {
             "gym": gym,

@@ -24,7 +24,8 @@ int oracle_default_params(int kind, int reading_2d, oracle_params *p) {
     p->mass = 1.0;      /* quadrotor3d.py:45, quadrotor2d.py:44 */
     p->load_mass = 0.1; /* quadrotor3d_slungload.py:46, quadrotor2d_slungload.py:45 */
     p->dt = 0.01;       /* quadrotor3d.py:46 */
-    p->g = 9.8;         /* quadrotor3d.py:47 g=(0,0,-9.8); quadrotor2d.py:46 g=(0,-9.8) */
+    p->g = 9.8;
+    p->g_vec[kind <= ORACLE_QUAD2D_SL ? 1 : 2] = -9.8; /* quadrotor3d.py:47 g=(0,0,-9.8); quadrotor2d.py:46 g=(0,-9.8) */
     p->thrust_scale = 1.0;
     p->clamp_thrust = 0;
     p->kp = -5.0; /* quadrotor3d.py:143, quadrotor2d.py:116 */
@@ -182,7 +183,7 @@ static void step_quad3d(const oracle_params *p, const double *s, const double *a
     double pos[3] = {s[0], s[1], s[2]};         /* :89 */
     double att[4] = {s[3], s[4], s[5], s[6]};   /* :90 */
     double vel[3] = {s[7], s[8], s[9]};         /* :91 */
-    double g[3] = {0.0, 0.0, -p->g};
+    const double *g = p->g_vec;                /* self.g */
     double qn[4], b3[3], acc[3], qd[4];
     quat_normalise(att, qn);                    /* :96 rotation_matrix normalises the Quaternion */
     quat_body_z(qn, b3);
@@ -211,7 +212,7 @@ static void step_quad3d_sl(const oracle_params *p, const double *s, const double
     double vel[3] = {s[7], s[8], s[9]};
     double lp[3] = {s[10], s[11], s[12]};
     double lv[3] = {s[13], s[14], s[15]};
-    double g[3] = {0.0, 0.0, -p->g};
+    const double *g = p->g_vec;                /* self.g */
     double tv[3], u[3], qn[4], b3[3], acc[3], qd[4], la[3];
     for (int i = 0; i < 3; ++i) tv[i] = lp[i] - pos[i];          /* :101 */
     double d = norm2(tv, 3);
@@ -272,7 +273,7 @@ static void step_quad2d(const oracle_params *p, const double *s, const double *a
     if (p->clamp_thrust && thrust < 0.0) thrust = 0.0;    /* :76-77 */
     double w = a[1];                                      /* :78 */
     double pos[2] = {s[0], s[1]}, att = s[2], vel[2] = {s[3], s[4]};
-    double g[2] = {0.0, -p->g};
+    const double *g = p->g_vec;                /* self.g (2 components) */
     double dir[2] = {cos(att + M_PI / 2), sin(att + M_PI / 2)};
     double acc[2];
     for (int i = 0; i < 2; ++i) acc[i] = thrust / p->mass * dir[i] + g[i];               /* :88 */
@@ -294,7 +295,7 @@ static void step_quad2d_sl(const oracle_params *p, const double *s, const double
     double w = a[1];
     double pos[2] = {s[0], s[1]}, att = s[2], vel[2] = {s[3], s[4]};
     double lp[2] = {s[5], s[6]}, lv[2] = {s[7], s[8]};
-    double g[2] = {0.0, -p->g};
+    const double *g = p->g_vec;                /* self.g (2 components) */
     double tv[2], u[2], la[2], acc[2];
     for (int i = 0; i < 2; ++i) tv[i] = lp[i] - pos[i];   /* :92 */
     double d = norm2(tv, 2);
@@ -362,7 +363,7 @@ static int control_3d(const oracle_params *p, const double *s, double *a_out) {
     double pos[3] = {s[0], s[1], s[2]};
     double att[4] = {s[3], s[4], s[5], s[6]};
     double vel[3] = {s[7], s[8], s[9]};
-    double g[3] = {0.0, 0.0, -p->g};
+    const double *g = p->g_vec;                /* self.g */
     double ad[3];
     for (int i = 0; i < 3; ++i) {
         double ep = pos[i] - p->ref_pos[i], ev = vel[i] - p->ref_vel[i]; /* :155-156 */
@@ -403,7 +404,7 @@ static int control_3d(const oracle_params *p, const double *s, double *a_out) {
 /* ---- Quadrotor2D.control  quadrotor2d.py:115-138 (= quadrotor2d_slungload.py:156-183) ---------- */
 static int control_2d(const oracle_params *p, const double *s, double *a_out) {
     double ad[2];
-    double g9[2] = {0.0, p->g};
+    const double g9[2] = {0.0, 9.8};              /* :130 a literal np.array([0.0, 9.8]), not self.g */
     for (int i = 0; i < 2; ++i) {
         double ep = s[i] - p->ref_pos[i], ev = s[3 + i] - p->ref_vel[i]; /* :127-128 */
         ad[i] = p->kp * ep + p->kv * ev + g9[i];                         /* :130 */

@@ -33,7 +33,7 @@ typedef struct oracle_params {
     double mass;          /* quadrotor3d.py:45 */
     double load_mass;     /* quadrotor3d_slungload.py:46 */
     double dt;            /* quadrotor3d.py:46 */
-    double g;             /* magnitude 9.8; gravity is (0,-g) / (0,0,-g)  quadrotor3d.py:47 */
+    double g;             /* |g_vec| = 9.8, informational (mirrors rmav_params.g); the dynamics read g_vec */
     double tether_length; /* quadrotor3d_slungload.py:58 (1.5), quadrotor2d_slungload.py:53 (0.5) */
     double pos_limit;     /* |pos| > pos_limit terminates */
     double vel_limit;     /* |vel| > vel_limit terminates */
@@ -42,6 +42,8 @@ typedef struct oracle_params {
     double ref_pos[3];    /* controller set-point */
     double ref_vel[3];
     double kp, kv, tau;   /* controller gains */
+    double g_vec[3];      /* self.g: (0,0,-9.8) quadrotor3d.py:47, quadrotor3d_slungload.py:48; 2-D kinds [0..1] = (0,-9.8)
+                             quadrotor2d.py:46, quadrotor2d_slungload.py:47.  Added as a vector like the reference does */
 } oracle_params;
 
 int oracle_state_dim(int kind);  /* 5, 9, 10, 16 */

@@ -57,11 +57,16 @@ int check_params(const rmav_params &q) {
         return rmav_fail(RMAV_ERR_INVALID, "rmav_params.integrator must be RMAV_INT_EULER or RMAV_INT_RK4");
     if (!(q.mass > 0) || !(q.dt > 0) || !(q.tau != 0) || !(q.mass + q.load_mass > 0))
         return rmav_fail(RMAV_ERR_INVALID, "rmav_params: mass, dt must be > 0 and tau != 0");
+    for (int i = 0; i < 3; ++i)
+        if (!(q.g_vec[i] == q.g_vec[i]) || q.g_vec[i] - q.g_vec[i] != 0.0)
+            return rmav_fail(RMAV_ERR_INVALID, "rmav_params.g_vec must be finite");
     return RMAV_OK;
 }
 
 // slots of the per-wavefront episode totals: one per 32 envs (the fp32-MFMA policy mode runs 32 envs per wavefront)
-inline size_t n_total_slots(int64_t n) { return (size_t)((n + 31) / 32); }
+// + 4: k_step reads its wavefront's slot in EVERY wavefront of the launch grid, also in those of the last 256-thread workgroup that lie
+// wholly past N (they add nothing and write nothing); the padding keeps those reads inside the array
+inline size_t n_total_slots(int64_t n) { return (size_t)((n + 31) / 32) + 4; }
 
 
 int ensure_scratch(rmav_handle h, size_t bytes) {
@@ -164,7 +169,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
     RolloutArgs a = a_in;
     take_armed_exchange(h, a, 64, publishes_start(MODE));
     const typename Env<K>::P p = derive_env<K>(h->params);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
     static_assert(!is_policy(MODE), "the policy-in-kernel rollouts are launched from rmav_policy_abi.hip");
     const size_t lds = (ST == ST_AOS_LDS) ? sizeof(float) * AosTile<Dims<K>::NS>::WORDS * (block_size(h) / 64) : 0;
     if constexpr (is_split(MODE)) {
@@ -250,9 +255,11 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
             constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : (MODE == ACT_BUFFER) ? ACT_BUFFER_SPLIT : ACT_CONTROLLER_SPLIT;
             int slices = 1;
             if (use_split(h, a, MODE != ACT_CONTROLLER, &slices, MODE == ACT_RANDOM)) {
-                const int st = pick_store_policy(h, a, true);
                 // balanced slices, each a multiple of 64 envs
                 const int64_t per = h->chunk > 0 ? h->chunk : slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;
+                RolloutArgs ap = a;
+                if (h->chunk > 0) ap.pitch = per;   // chunk-major columns are `chunk` (a multiple of 64) apart whatever N is
+                const int st = pick_store_policy(h, ap, true);
                 for (int64_t first = 0; first < h->n; first += per) {
                     RolloutArgs b = a;
                     if (slices > 1 || h->chunk > 0) {
@@ -324,7 +331,7 @@ inline int step_store(rmav_handle h) {
 template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctrl) {
     if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;   // the armed launch's snapshot is no longer the latest
     const typename Env<K>::P p = derive_env<K>(h->params);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
     const int st = step_store(h), bs = step_block(h);
     const bool lazy = step_lazy(h);
     const dim3 grid((unsigned)((h->n + bs - 1) / bs));
@@ -406,7 +413,7 @@ int launch_reset(rmav_handle h, float *obs_dev, int layout) {
 
 int launch_control(rmav_handle h, float *act_dev, int layout) {
     const uint32_t fl = (layout == RMAV_AOS ? F_AOS : 0u);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
 #define RMAV_CTRL_CASE(KIND)                                                                       \
     hipLaunchKernelGGL((k_control<KIND>), grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,    \
                        h->n, act_dev, fl, pc, h->pe[0], h->pe[1], h->pe[2])
@@ -506,6 +513,8 @@ int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
     p->load_mass = 0.1;
     p->dt = 0.01;
     p->g = 9.8;
+    // self.g: (0, 0, -9.8) quadrotor3d.py:47, quadrotor3d_slungload.py:48; (0, -9.8) quadrotor2d.py:46, quadrotor2d_slungload.py:47
+    p->g_vec[(kind == RMAV_QUAD2D || kind == RMAV_QUAD2D_SL) ? 1 : 2] = -9.8;
     p->thrust_scale = 1.0;
     p->kp = -5.0;
     p->kv = -4.0;
@@ -543,6 +552,7 @@ int rmav_default_params(int kind, int reading_2d, rmav_params *p) {
         p->mass = 0.1800;
         p->load_mass = 0.0;
         p->g = 9.8100;
+        p->g_vec[2] = 0.0;   // not read: ReinmavEnv's gravity is the scalar above
         p->dt = 1.0 / 100;
         p->tau = 1.0;        // unused (keeps check_params happy)
         p->act_lo = 0.0;     // RMAV_ACT_RANDOM range for (F, Mx, My, Mz): [0, max_force)
@@ -965,7 +975,9 @@ int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const 
 int64_t rmav_chunk_envs(rmav_handle h) {
     if (!valid(h)) return rmav_fail(RMAV_ERR_INVALID, "invalid handle");
     // measured: quadrotor3d with random / caller actions gains 5 - 9 % at 131 072 - 262 144 envs; every other kind loses 3 - 10 %
-    return (h->kind == RMAV_QUAD3D && h->n > 65536) ? 65536 : h->n;
+    // no chunking: ONE chunk whose width is N rounded up to the 64-env granule every chunk width must have (rmav_rollout_chunked
+    // turns a chunk wider than N into the column pitch of the plain layout)
+    return (h->kind == RMAV_QUAD3D && h->n > 65536) ? 65536 : ((h->n + 63) & ~(int64_t)63);
 }
 
 int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
@@ -979,6 +991,8 @@ int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const 
     const int64_t cap = kEnvsPerCuSlot * (action_mode == RMAV_ACT_CONTROLLER ? kSplitPairsController : kSplitPairsRandom)[h->kind];
     if (n_steps < 2 || chunk_envs > cap)
         return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts need n_steps >= 2 and chunk_envs <= %lld for this kind and action source", (long long)cap);
+    if (actions_out && action_mode == RMAV_ACT_BUFFER)   // (rollout_impl's echo copy is sized for the plain layout)
+        return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts do not echo caller actions: pass actions_out = NULL with RMAV_ACT_BUFFER");
     h->chunk = chunk_envs;
     const int rc = rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE, RMAV_SOA, 1);
     h->chunk = 0;

@@ -9,7 +9,8 @@
 
 namespace rmav {
 
-template <typename R> inline ParamsT<R> derive(const rmav_params &q) {
+// two_d: the 2-D kinds, whose controller adds the literal (0, 9.8) (quadrotor2d.py:130) whatever self.g is
+template <typename R> inline ParamsT<R> derive(const rmav_params &q, bool two_d) {
     ParamsT<R> p;
     memset(&p, 0, sizeof(p));
     p.inv_mass = (R)(1.0 / q.mass);
@@ -18,7 +19,10 @@ template <typename R> inline ParamsT<R> derive(const rmav_params &q) {
     p.inv_mtot = (R)(1.0 / (q.mass + q.load_mass));
     p.dt = (R)q.dt;
     p.half_dt2 = (R)(0.5 * q.dt * q.dt);
-    p.g = (R)q.g;
+    for (int i = 0; i < 3; ++i) {
+        p.gv[i] = (R)q.g_vec[i];
+        p.ff[i] = two_d ? (R)(i == 1 ? 9.8 : 0.0) : (R)(-q.g_vec[i]);
+    }
     p.L = (R)q.tether_length;
     p.mL = (R)(q.mass * q.tether_length);
     p.pos_limit = (R)q.pos_limit;
@@ -74,7 +78,7 @@ inline ReinmavP derive_reinmav(const rmav_params &q) {
 
 template <int K> inline typename Env<K>::P derive_env(const rmav_params &q) {
     if constexpr (K == REINMAV) return derive_reinmav(q);
-    else return derive<typename Env<K>::R>(q);
+    else return derive<typename Env<K>::R>(q, K == QUAD2D || K == QUAD2D_SL);
 }
 
 }  // namespace rmav

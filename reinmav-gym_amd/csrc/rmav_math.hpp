@@ -103,7 +103,8 @@ template <typename R> struct ParamsT {
     R inv_mtot;      // 1/(mass+load_mass)
     R dt;
     R half_dt2;      // 0.5*dt*dt
-    R g;
+    R gv[3];         // gravity VECTOR (quadrotor3d.py:47 self.g = (0, 0, -9.8); 2-D kinds: (0, -9.8), quadrotor2d.py:46), added component-wise
+    R ff[3];         // controller feed-forward: 3-D kinds -self.g (quadrotor3d.py:162), 2-D kinds the LITERAL (0, 9.8) of quadrotor2d.py:130
     R L;             // tether length
     R mL;            // mass * tether length
     R pos_limit, vel_limit;
@@ -259,7 +260,7 @@ template <> struct Env<QUAD3D> {
         quat_normalise(q, qn);                       // :96 rotation_matrix normalises
         quat_body_z(qn, b);
         const R k = a[0] * p.inv_mass;               // :96 thrust/mass
-        const R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};
+        const R acc[3] = {rfma(k, b[0], p.gv[0]), rfma(k, b[1], p.gv[1]), rfma(k, b[2], p.gv[2])};   // :96 ... + self.g
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const R v = s[7 + i];
@@ -301,8 +302,8 @@ template <> struct Env<QUAD3D_SL> {
         const R dd = rfma(tv[0], tv[0], rfma(tv[1], tv[1], tv[2] * tv[2]));
         const bool taut = dd >= p.L * p.L;                                    // :104  |tv| >= L, without the root
         const R k = thrust * p.inv_mass;
-        R acc[3] = {k * b[0], k * b[1], rfma(k, b[2], -p.g)};                 // :118 / :140
-        R la[3] = {R(0), R(0), -p.g};                                         // :134 slack: a_l = g
+        R acc[3] = {rfma(k, b[0], p.gv[0]), rfma(k, b[1], p.gv[1]), rfma(k, b[2], p.gv[2])};   // :118 / :140
+        R la[3] = {p.gv[0], p.gv[1], p.gv[2]};                                // :134 slack: a_l = g
         if (taut) {
             const R inv_d = inv_sqrt(dd);
             const R u[3] = {tv[0] * inv_d, tv[1] * inv_d, tv[2] * inv_d};     // :102
@@ -311,9 +312,9 @@ template <> struct Env<QUAD3D_SL> {
             const R sc = rfma(u[0], rfma(thrust, b[0], -c),
                               rfma(u[1], rfma(thrust, b[1], -c), u[2] * rfma(thrust, b[2], -c)));
             const R f = sc * p.inv_mtot;                                      // :111
-            la[0] = f * u[0];
-            la[1] = f * u[1];
-            la[2] = rfma(f, u[2], -p.g);
+            la[0] = rfma(f, u[0], p.gv[0]);
+            la[1] = rfma(f, u[1], p.gv[1]);
+            la[2] = rfma(f, u[2], p.gv[2]);
             // :115 T = m_l * |a_l - g| * u ;  a_l - g = f*u with |u| = 1, so the norm is |f| (to ~1e-15; no root needed)
             const R tn = p.load_mass * rabs(f);
 #pragma unroll
@@ -396,7 +397,7 @@ template <> struct Env<QUAD2D> {
         fast_sincosf(s[2], sn, cs);
         // (cos(th+pi/2), sin(th+pi/2)) = (-sin th, cos th)      :88
         const R k = thrust * p.inv_mass;
-        const R acc[2] = {k * (-sn), rfma(k, cs, -p.g)};
+        const R acc[2] = {rfma(k, -sn, p.gv[0]), rfma(k, cs, p.gv[1])};   // :88 ... + self.g
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const R v = s[3 + i];
@@ -430,16 +431,16 @@ template <> struct Env<QUAD2D_SL> {
         const R dd = rfma(tv[0], tv[0], tv[1] * tv[1]);
         const bool taut = dd >= p.L * p.L;                        // :95  |tv| >= L, without the root
         const R k = thrust * p.inv_mass;
-        R acc[2] = {k * dir[0], rfma(k, dir[1], -p.g)};           // :107 / :128
-        R la[2] = {R(0), -p.g};                                   // :123
+        R acc[2] = {rfma(k, dir[0], p.gv[0]), rfma(k, dir[1], p.gv[1])};   // :107 / :128
+        R la[2] = {p.gv[0], p.gv[1]};                             // :123
         if (taut) {
             const R inv_d = inv_sqrt(dd);
             const R u[2] = {tv[0] * inv_d, tv[1] * inv_d};        // :93
             const R c = p.mL * rfma(lv[0], lv[0], lv[1] * lv[1]);
             const R sc = rfma(u[0], rfma(thrust, dir[0], -c), u[1] * rfma(thrust, dir[1], -c));  // :97
             const R f = sc * p.inv_mtot;                          // :98
-            la[0] = f * u[0];
-            la[1] = rfma(f, u[1], -p.g);
+            la[0] = rfma(f, u[0], p.gv[0]);
+            la[1] = rfma(f, u[1], p.gv[1]);
             const R tn = p.load_mass * rabs(f);                   // :102 |a_l - g| = |f u| = |f|
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[i] = rfma(tn * u[i], p.inv_mass, acc[i]);
@@ -483,8 +484,7 @@ RMAV_HD void control_3d(const float (&s)[NS], const ParamsT<double> &p, float (&
     R ad[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)                                   // :155-162
-        ad[i] = rfma(p.kp, (R)s[i] - p.ref_pos[i], p.kv * ((R)s[7 + i] - p.ref_vel[i]));
-    ad[2] += p.g;                                                 // - g, g = (0,0,-9.8)
+        ad[i] = rfma(p.kp, (R)s[i] - p.ref_pos[i], p.kv * ((R)s[7 + i] - p.ref_vel[i])) + p.ff[i];   // :162 ... - self.g
     // acc2quat :127-141 ; yc = (0,1,0)
     const R inv_n = inv_sqrt(rfma(ad[0], ad[0], rfma(ad[1], ad[1], ad[2] * ad[2])));
     R zb[3] = {ad[0] * inv_n, ad[1] * inv_n, ad[2] * inv_n};
@@ -582,8 +582,9 @@ RMAV_HD double fast_atan2(double y, double x) {
 template <int NS>
 RMAV_HD void control_2d(const float (&s)[NS], const ParamsT<double> &p, float (&a)[2]) {
     using R = double;
-    const R ax = rfma(p.kp, (R)s[0] - p.ref_pos[0], p.kv * ((R)s[3] - p.ref_vel[0]));
-    const R ay = rfma(p.kp, (R)s[1] - p.ref_pos[1], p.kv * ((R)s[4] - p.ref_vel[1])) + p.g;  // :130
+    // :130 "+ np.array([0.0, 9.8])": a literal in the reference, NOT self.g - ff carries it
+    const R ax = rfma(p.kp, (R)s[0] - p.ref_pos[0], p.kv * ((R)s[3] - p.ref_vel[0])) + p.ff[0];
+    const R ay = rfma(p.kp, (R)s[1] - p.ref_pos[1], p.kv * ((R)s[4] - p.ref_vel[1])) + p.ff[1];
     const R th_d = fast_atan2(ay, ax) - R(1.5707963267948966);    // :131
     a[1] = (float)(p.neg_inv_tau * ((R)s[2] - th_d));             // :132-133
     a[0] = (float)(p.mass * root(rfma(ax, ax, ay * ay)));   // :134

@@ -21,7 +21,7 @@ template <int K, int MODE> int launch_policy_1w(rmav_handle h, const RolloutArgs
     RolloutArgs a = a_in;
     take_armed_exchange(h, a, MODE == ACT_POLICY_F32M ? 32 : 64);
     const typename Env<K>::P p = derive_env<K>(h->params);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
     const size_t lds = sizeof(float) * (MODE == ACT_POLICY ? (size_t)PolicyLayout<Dims<K>::NS>::TOTAL
                                         : MODE == ACT_POLICY_BF16 ? (size_t)MfmaLayout::TOTAL : (size_t)Mfma32Layout::TOTAL);
     const int64_t per_wg = MODE == ACT_POLICY_F32M ? block_size(h) / 2 : block_size(h);
@@ -36,7 +36,7 @@ template <int K, int FMT> int launch_rollout_pair(rmav_handle h, const RolloutAr
     RolloutArgs a = a_in;
     take_armed_exchange(h, a, 64);
     const typename Env<K>::P p = derive_env<K>(h->params);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
     const int forced = h->tune[RMAV_TUNE_PAIR_GROUP];
     // measured (profiles/r04/actor_bench.txt, quadrotor3d x 32 steps): 65 536 envs 4 pairs 15.0 G env-steps/s, 2 pairs 14.1, 1 pair 13.7
     // (one workgroup per CU, weights staged once per CU); 131 072 envs 2 pairs 15.8 - 16.7, 4 pairs 15.5 - 16.3, 1 pair 11.1
@@ -52,7 +52,7 @@ template <int K> int launch_rollout_pair_shared(rmav_handle h, const RolloutArgs
     RolloutArgs a = a_in;
     take_armed_exchange(h, a, 64);
     const typename Env<K>::P p = derive_env<K>(h->params);
-    const ParamsT<double> pc = derive<double>(h->params);
+    const ParamsT<double> pc = derive<double>(h->params, h->kind == RMAV_QUAD2D || h->kind == RMAV_QUAD2D_SL);
     const int forced = h->tune[RMAV_TUNE_PAIR_GROUP];
     // measured (profiles/r04/actor_bench.txt): 65 536 envs 1 / 2 / 4 pairs per workgroup 20.8 / 21.5 / 20.4 G env-steps/s, 131 072: 19.9 / 25.9 / 26.1
     const int g = (forced >= 1 && forced <= kPairGroupMax) ? forced : 2;

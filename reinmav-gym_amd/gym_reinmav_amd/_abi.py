@@ -57,6 +57,7 @@ class Params(C.Structure):
         ("tau", C.c_double),
         ("act_lo", C.c_double),
         ("act_hi", C.c_double),
+        ("g_vec", C.c_double * 3),
     ]
 
 
@@ -151,7 +152,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.rmav_version() != 100:
+        if L.rmav_version() != 101:
             raise RmavError(ERR_INVALID, "librmav.so version mismatch; rebuild")
         _lib = L
     return _lib

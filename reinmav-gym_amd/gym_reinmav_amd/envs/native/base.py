@@ -135,7 +135,7 @@ class NativeQuadrotorEnv(_EnvBase):
     def _set_param(self, **kv):
         p = self._batch.params
         for k, v in kv.items():
-            if k in ("ref_pos", "ref_vel"):
+            if k in ("ref_pos", "ref_vel", "g_vec"):
                 v = np.asarray(v, dtype=np.float64).reshape(-1)
                 if v.shape != (self._dim,):
                     raise ValueError(f"{k} must have {self._dim} components")
@@ -164,7 +164,7 @@ class NativeQuadrotorEnv(_EnvBase):
         return np.array(list(getattr(self._batch.params, name))[:self._dim], dtype=np.float64)
 
     def _read_g(self):
-        return np.array([0.0] * (self._dim - 1) + [-self._batch.params.g])
+        return self._read_vec("g_vec")
 
     mass = property(lambda self: self._batch.params.mass, lambda self, v: self._set_param(mass=v))
     dt = property(lambda self: self._batch.params.dt, lambda self, v: self._set_param(dt=v))
@@ -190,7 +190,7 @@ class NativeQuadrotorEnv(_EnvBase):
 
     @property
     def g(self):
-        """Gravity vector (0, [0,] -g) like quadrotor3d.py:47; only its vertical component can be non-zero here."""
+        """Gravity VECTOR like quadrotor3d.py:47 / quadrotor2d.py:46: any direction, read by every step() (and by the 3-D control())."""
         return self._vec(self._read_g, self._set_g)
 
     @g.setter
@@ -198,10 +198,7 @@ class NativeQuadrotorEnv(_EnvBase):
         self._set_g(v)
 
     def _set_g(self, v):
-        v = np.asarray(v, dtype=np.float64).reshape(-1)
-        if v.shape != (self._dim,) or np.any(v[:-1] != 0.0):
-            raise ValueError("g must be (0, " + ("0, " if self._dim == 3 else "") + "-g): the device path models vertical gravity only")
-        self._set_param(g=-float(v[-1]))
+        self._set_param(g_vec=v)
 
     @property
     def ref_pos(self):

@@ -15,7 +15,7 @@ template <int K>
 void step_k(const rmav_params &q, float *s, const float *a, float *dist, int *done) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     using R = typename Env<K>::R;
-    const ParamsT<R> p = derive<R>(q);
+    const ParamsT<R> p = derive<R>(q, K == QUAD2D || K == QUAD2D_SL);
     float ss[NS], aa[NA];
     for (int i = 0; i < NS; ++i) ss[i] = s[i];
     for (int i = 0; i < NA; ++i) aa[i] = a[i];
@@ -26,7 +26,7 @@ void step_k(const rmav_params &q, float *s, const float *a, float *dist, int *do
 }
 template <int K> void control_k(const rmav_params &q, const float *s, float *a) {
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
-    const ParamsT<double> p = derive<double>(q);
+    const ParamsT<double> p = derive<double>(q, K == QUAD2D || K == QUAD2D_SL);
     float ss[NS], aa[NA];
     for (int i = 0; i < NS; ++i) ss[i] = s[i];
     env_control<K>(ss, p, aa);

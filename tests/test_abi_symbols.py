@@ -30,7 +30,7 @@ def test_library_level_queries(built):
     from gym_reinmav_amd import _abi as A
 
     L = A.lib()
-    assert L.rmav_version() == 100
+    assert L.rmav_version() == 101
     assert [L.rmav_state_dim(k) for k in range(5)] == [5, 9, 10, 16, 13]
     assert [L.rmav_action_dim(k) for k in range(5)] == [2, 2, 4, 4, 4]
     assert [L.rmav_algorithmic_bytes(k) for k in range(5)] == [53, 85, 101, 149, 125]
@@ -57,7 +57,8 @@ def test_default_params_match_oracle_defaults(built):
             for f in ("mass", "load_mass", "dt", "g", "tether_length", "pos_limit", "vel_limit", "thrust_scale",
                       "clamp_thrust", "kp", "kv", "tau"):
                 assert getattr(p, f) == getattr(q, f), (name, f)
-            assert list(p.ref_pos) == list(q.ref_pos) and list(p.ref_vel) == list(q.ref_vel)
+            assert list(p.ref_pos) == list(q.ref_pos) and list(p.ref_vel) == list(q.ref_vel) and list(p.g_vec) == list(q.g_vec)
+            assert list(p.g_vec) == ([0.0, -9.8, 0.0] if name.startswith("quad2d") else [0.0, 0.0, -9.8])
 
 
 def test_no_cpu_fallback(built):

@@ -148,7 +148,7 @@ def test_gym_env_public_attributes_write_through(G):
     env.ref_vel = [0.1, 0.0, -0.1]
     env.dt = 0.02
     env.g = np.array([0.0, 0.0, -3.7])
-    p.ref_vel[0], p.ref_vel[2], p.dt, p.g = 0.1, -0.1, 0.02, 3.7
+    p.ref_vel[0], p.ref_vel[2], p.dt, p.g_vec[2] = 0.1, -0.1, 0.02, -3.7
     assert list(env.g) == [0.0, 0.0, -3.7] and env.dt == 0.02
     a3 = env.control()
     ctrl_close(a3, O.control("quad3d", obs, p))
@@ -159,8 +159,21 @@ def test_gym_env_public_attributes_write_through(G):
     assert env.pos_threshold == 0.01
     _, _, d3, _ = env.step(a3)
     assert d3 is True
+    env.pos_threshold = 3.0
+    env.g = (1.0, -0.5, -9.0)                           # the reference's self.g is a free 3-vector (quadrotor3d.py:47,96-99,162)
+    env.g[1] = 0.25                                     # ... and so are its elements
+    p.pos_limit, p.g_vec[0], p.g_vec[1], p.g_vec[2] = 3.0, 1.0, 0.25, -9.0
+    assert list(env.g) == [1.0, 0.25, -9.0]
+    s_t = np.asarray(env.state, dtype=np.float64)
+    a4 = env.control()
+    ctrl_close(a4, O.control("quad3d", s_t, p))
+    o4, _, _, _ = env.step(a4)
+    s4, _, _, _ = O.step("quad3d", s_t, a4.astype(np.float32).astype(np.float64), None, p)
+    assert_close(o4, s4, STATE_TOL)
     with pytest.raises(ValueError):
-        env.g = (1.0, 0.0, -9.8)                        # only vertical gravity on the device path
+        env.g = (0.0, -9.8)                             # wrong length
+    with pytest.raises(G._abi.RmavError):
+        env.g = (0.0, float("nan"), -9.8)               # rmav_set_params validates
     with pytest.raises(ValueError):
         env.ref_pos = (1.0, 2.0)
     with pytest.raises(G._abi.RmavError):
@@ -186,10 +199,15 @@ def test_gym_env_public_attributes_write_through(G):
     e2.ref_pos = (0.5, -0.25)
     e2.g = (0.0, -5.0)
     p2 = O.default_params("quad2d")
-    p2.ref_pos[0], p2.ref_pos[1], p2.g = 0.5, -0.25, 5.0
+    p2.ref_pos[0], p2.ref_pos[1], p2.g_vec[1] = 0.5, -0.25, -5.0   # 2-D control() keeps the literal (0, 9.8) (quadrotor2d.py:130)
     s0 = e2.reset()
     a = e2.control()
     ctrl_close(a, O.control("quad2d", s0, p2))
+    e2.g = (0.75, -5.0)
+    p2.g_vec[0] = 0.75
+    o2d, _, _, _ = e2.step(a)
+    s2d, _, _, _ = O.step("quad2d", s0, a.astype(np.float32).astype(np.float64), None, p2)
+    assert_close(o2d, s2d, STATE_TOL)
     e2.close()
 
 

@@ -93,6 +93,46 @@ def test_step_vs_oracle_random_device_buffers(G, kind, layout):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_tilted_gravity_matches_the_oracle(G, kind):
+    """The reference's self.g is a public VECTOR read by every step() (quadrotor3d.py:47,96-99; quadrotor2d.py:46,88) and by the
+    3-D control() (:162); the 2-D control() keeps its literal (0, 9.8) (quadrotor2d.py:130).  rmav_params.g_vec carries it:
+    single step, control(), and the fused controller-driven rollout against the oracle run with the same vector."""
+    n = 20000 + 11
+    s, a = random_cases(kind, n, seed=77)
+    dim = 2 if kind.startswith("quad2d") else 3
+    gv = [1.25, -0.75, -8.5][:dim] if dim == 3 else [1.25, -8.5]
+    env = G.BatchedQuadrotor(kind, n, auto_reset=False, track_episodes=False)
+    p, q = env.params, O.default_params(kind)
+    for i in range(dim):
+        p.g_vec[i] = q.g_vec[i] = gv[i]
+    env.params = p
+    assert list(env.params.g_vec)[:dim] == gv
+    env.set_state(s)
+    ctrl = env.control()
+    assert scaled_err(ctrl[::9], O.batch_control(kind, s[::9].astype(np.float64), params=q)).max() <= CTRL_TOL
+    obs, rew, done = env.step(a)
+    o2, *_ = _check_step(kind, s, a, obs, rew, done, params=q)
+    # the default vector gives something else (the test would not notice a g_vec the kernels ignore)
+    o_def, *_ = O.batch_step(kind, s.astype(np.float64), a.astype(np.float64))
+    assert scaled_err(o2, o_def).max() > 1e-4
+    # fused controller-driven rollout = the same single steps, teacher-forced per step against the oracle
+    env.set_state(s)
+    env.set_sbd(np.full(n, -1, np.int32))
+    tr = env.rollout(6, mode="controller", layout="aos", want=("actions", "obs", "rew", "done"))
+    prev = s.astype(np.float64)
+    for k in range(6):
+        act = tr["actions"][k]
+        assert scaled_err(act[::9], O.batch_control(kind, prev[::9], params=q)).max() <= CTRL_TOL
+        o_k, r_k, d_k, _ = O.batch_step(kind, prev, act.astype(np.float64), params=q)
+        fin = np.isfinite(o_k).all(axis=1)
+        if kind.endswith("_sl"):   # tether edge: the branch is decided by the last bit of a norm (see oracle_step_branch)
+            fin &= np.abs(O.tether_slack(kind, prev, q)) > 1e-5
+        assert scaled_err(tr["obs"][k][fin], o_k[fin]).max() <= 2e-6
+        prev = tr["obs"][k].astype(np.float64)
+    env.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_control_vs_reference_golden(G, kind, golden):
     g = golden[kind]
     env = G.BatchedQuadrotor(kind, len(g["ctrl_s"]), auto_reset=False, track_episodes=False)
@@ -809,6 +849,31 @@ def test_chunked_rollout_equals_the_plain_layout(G, kind, n, chunk, T, mode):
     ref_env.close()
 
 
+@pytest.mark.parametrize("kind,n", [("quad2d", 4099), ("quad3d", 5000), ("quad3d_sl", 63), ("quad3d", 65536 + 77)])
+def test_chunked_rollout_default_chunk_for_any_batch_size(G, kind, n):
+    """rmav_chunk_envs() is always a value rmav_rollout_chunked accepts (it returned N itself, which the multiple-of-64
+    check refused whenever N % 64 != 0): the default call works for every batch size and equals the plain rollout."""
+    import torch
+
+    env = G.BatchedQuadrotor(kind, n, seed=3, auto_reset=True, track_episodes=True)
+    ref_env = G.BatchedQuadrotor(kind, n, seed=3, auto_reset=True, track_episodes=True)
+    ch = int(env._lib.rmav_chunk_envs(env._h))
+    assert ch % 64 == 0 and (ch == 65536 if (kind == "quad3d" and n > 65536) else ch == (n + 63) // 64 * 64)
+    tr = env.rollout_chunked(5, mode="random", want=("actions", "obs", "rew", "done"))          # chunk = None: the recommendation
+    ref = ref_env.rollout(5, mode="random", layout="soa", want=("actions", "obs", "rew", "done"), device_out=True)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert torch.equal(env.unchunk(tr[k]), ref[k]), k
+    # direct C callers: a caller-action echo would be sized for the plain layout - refused in chunk-major mode
+    from gym_reinmav_amd import _abi as A
+    if n > 128:
+        a = torch.zeros((-(-n // 64), 5, NA[kind], 64), device="cuda")
+        with pytest.raises(A.RmavError):
+            A.check(env._lib.rmav_rollout_chunked(env._h, 5, A.ACT_BUFFER, a.data_ptr(), a.data_ptr() + 4, None, None, None, 64))
+    env.close()
+    ref_env.close()
+
+
 def test_chunked_rollout_rejects_bad_arguments(G):
     from gym_reinmav_amd import _abi as A
 
@@ -822,7 +887,7 @@ def test_chunked_rollout_rejects_bad_arguments(G):
         env.rollout_chunked(8, chunk=196608)          # beyond the two-wavefront kernel's capacity
     env.close()
     small = G.BatchedQuadrotor("quad2d", 200000, seed=1)
-    assert int(small._lib.rmav_chunk_envs(small._h)) == 200000   # only quadrotor3d's launches are store-bound: one chunk = the plain layout
+    assert int(small._lib.rmav_chunk_envs(small._h)) == 200000   # only quadrotor3d's launches are store-bound: one chunk = the plain layout (N is a multiple of 64 here)
     small.close()
 
 

@@ -169,12 +169,12 @@ def test_bench_device_sampler_summary():
 def test_public_attributes_write_through_mechanics():
     """The gym-shaped env's vector-valued attributes (ref_pos, ref_vel, g) without a GPU: a fake handle in place of BatchedQuadrotor.
     Whole-array assignment, element writes on the handed-out array (applied to the CURRENT value, also from a stale snapshot),
-    arithmetic yields plain ndarrays, g accepts only vertical gravity, every write drops the cached control() action."""
+    arithmetic yields plain ndarrays, g is a free vector, every write drops the cached control() action."""
     from gym_reinmav_amd.envs.native import base as B
 
     class P:
         def __init__(self):
-            self.ref_pos, self.ref_vel, self.g, self.mass, self.load_mass = [0.0, 0.0, 2.0], [0.0, 0.0, 0.0], 9.8, 1.0, 0.1
+            self.ref_pos, self.ref_vel, self.g_vec, self.mass, self.load_mass = [0.0, 0.0, 2.0], [0.0, 0.0, 0.0], [0.0, 0.0, -9.8], 1.0, 0.1
 
     class FakeBatch:
         def __init__(self):
@@ -203,11 +203,12 @@ def test_public_attributes_write_through_mechanics():
     assert e.mass == 1.3 and list(e.g) == [0.0, 0.0, -9.8]
     e.g[2] = -3.7
     assert list(e.g) == [0.0, 0.0, -3.7]
-    with pytest.raises(ValueError):
-        e.g[0] = 1.0
+    e.g[0] = 1.0                                 # any direction, like the reference's self.g
     with pytest.raises(ValueError):
         e.ref_vel = (1.0, 2.0)
-    assert list(e.g) == [0.0, 0.0, -3.7]
+    with pytest.raises(ValueError):
+        e.g = (0.0, -9.8)
+    assert list(e.g) == [1.0, 0.0, -3.7]
     with pytest.raises(AttributeError):
         e.load_mass                              # noqa: B018 - not a slung-load class
     e._has_load = True

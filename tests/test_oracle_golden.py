@@ -133,6 +133,40 @@ def test_reset_distribution(kind, built):
     assert a.shape == (2048, NA[kind]) and a.min() >= 0.0 and a.max() < 10.0 and abs(a.mean() - 5) < 0.2
 
 
+def test_quaternion_stand_in_against_independent_implementations():
+    """SURVEY 8c's one soft link: pyquaternion (requirements.txt:1, call sites quadrotor3d.py:94,96,101-102,139,166-169,176) is
+    absent from the reference tree and from this image, so the reference's 3-D rows run on ref_harness's restatement of its
+    0.9.x algorithm.  Every member of row a10 is checked against an independent implementation (SciPy's Rotation for
+    rotation_matrix / __mul__ / Quaternion(matrix=), a component-wise Hamilton product for derivative) - needs no reference tree."""
+    import ref_harness as rh
+
+    e_rot, e_mul, e_mat, e_der = rh.selfcheck_quaternion(1500)
+    assert e_rot < 1e-14 and e_mul < 1e-14 and e_mat < 1e-14 and e_der < 1e-14, (e_rot, e_mul, e_mat, e_der)
+    # members with a fixed answer: copies do not normalise, Quaternion(Quaternion) shares storage, rotation_matrix normalises
+    # self.q IN PLACE (what makes quadrotor3d.py:101's derivative see the unit quaternion), conjugate does not
+    q = rh.Quaternion([2.0, 0.0, 0.0, 0.0])
+    assert list(q.elements) == [2.0, 0.0, 0.0, 0.0] and rh.Quaternion(q).q is q.q
+    assert list(q.conjugate.elements) == [2.0, -0.0, -0.0, -0.0]
+    q.rotation_matrix
+    assert list(q.elements) == [1.0, 0.0, 0.0, 0.0]
+    almost = rh.Quaternion([1.0 + 1e-15, 0.0, 0.0, 0.0])      # |1 - |q|^2| < 1e-14: left alone
+    almost.rotation_matrix
+    assert almost.elements[0] == 1.0 + 1e-15
+    with pytest.raises(ValueError):
+        rh.Quaternion(matrix=np.eye(3) * 1.01)                 # the orthogonality check of the real package
+
+
+def test_quaternion_stand_in_equals_the_real_package_when_it_is_importable():
+    """Self-enabling: with the real pyquaternion importable (not in this image) the harness runs the reference on it
+    (ref_harness._install_stubs) and the stand-in must agree with it member by member."""
+    import ref_harness as rh
+
+    diffs = rh.compare_with_real(1000)
+    if diffs is None:
+        pytest.skip("pyquaternion is not installed here: the stand-in is checked against SciPy only")
+    assert max(diffs.values()) < 1e-15, diffs
+
+
 def test_oracle_vs_live_reference(built):
     """Authoring container only: the oracle against the reference files executed now."""
     import ref_harness as rh
