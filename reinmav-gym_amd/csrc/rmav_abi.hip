@@ -375,12 +375,9 @@ RolloutArgs base_args(rmav_handle h) {
     a.state = h->state;
     a.n = h->n;
     a.pitch = h->n;
-    a.sbd = h->sbd;
-    a.reset_cnt = h->reset_cnt;
+    a.rec = h->rec;
     a.ep_ret = h->ep_ret;
-    a.ep_start = h->ep_start;
     a.last_ret = h->last_ret;
-    a.last_len = h->last_len;
     a.totals = h->totals;
     a.env_time = h->env_time;
     for (int i = 0; i < 3; ++i) a.pe[i] = h->pe[i];
@@ -398,7 +395,7 @@ int launch_reset(rmav_handle h, float *obs_dev, int layout) {
     const uint32_t fl = (h->flags & F_TRACK) | (layout == RMAV_AOS ? F_AOS : 0u);
 #define RMAV_RESET_CASE(KIND)                                                                      \
     hipLaunchKernelGGL((k_reset<KIND>), grid_for(h), dim3(block_size(h)), 0, h->stream, h->state,      \
-                       h->n, h->reset_cnt, h->ep_ret, h->ep_start, (uint32_t)h->t, obs_dev, h->seed, h->env_base, fl)
+                       h->n, h->rec, h->ep_ret, (uint32_t)h->t, obs_dev, h->seed, h->env_base, fl)
     switch (h->kind) {
     case RMAV_QUAD2D: RMAV_RESET_CASE(QUAD2D); break;
     case RMAV_QUAD2D_SL: RMAV_RESET_CASE(QUAD2D_SL); break;
@@ -462,6 +459,34 @@ template <typename T> int copy_in(rmav_handle h, T *dev, const T *in, size_t cou
         HIP_TRY(hipMemcpyAsync(dev, in, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    return RMAV_OK;
+}
+
+// One 32-bit field of the per-env records (EnvRec: 0 sbd, 1 reset_cnt, 2 ep_start, 3 last_len) as a dense array: the state accessors
+// of the ABI gather / scatter it with one small kernel (host pointers: through device scratch)
+int rec_field_get(rmav_handle h, int field, uint32_t *out, int mem) {
+    if (!out) return rmav_fail(RMAV_ERR_INVALID, "output pointer is NULL");
+    const size_t n = (size_t)h->n;
+    uint32_t *dst = out;
+    if (mem != RMAV_DEVICE) {
+        if (int rc = ensure_scratch(h, n * sizeof(uint32_t))) return rc;
+        dst = (uint32_t *)h->scratch;
+    }
+    hipLaunchKernelGGL(k_rec_get, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, (const EnvRec *)h->rec, field, (int64_t)n);
+    HIP_TRY(hipGetLastError());
+    return mem == RMAV_DEVICE ? RMAV_OK : copy_out(h, (const uint32_t *)dst, out, n, RMAV_HOST);
+}
+int rec_field_set(rmav_handle h, int field, const uint32_t *in, int mem) {
+    if (!in) return rmav_fail(RMAV_ERR_INVALID, "input pointer is NULL");
+    const size_t n = (size_t)h->n;
+    const uint32_t *src = in;
+    if (mem != RMAV_DEVICE) {
+        if (int rc = ensure_scratch(h, n * sizeof(uint32_t))) return rc;
+        if (int rc = copy_in(h, (uint32_t *)h->scratch, in, n, RMAV_HOST)) return rc;
+        src = (const uint32_t *)h->scratch;
+    }
+    hipLaunchKernelGGL(k_rec_set, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->rec, src, field, (int64_t)n);
+    HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
 
@@ -618,14 +643,11 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         const bool tr = (flags & RMAV_F_TRACK_EPISODES) != 0;
         size_t off = 0;
         const size_t o_state = off; off += up(n * nS * sizeof(float));
-        const size_t o_sbd = off; off += up(n * sizeof(int32_t));
-        const size_t o_rc = off; off += up(n * sizeof(uint32_t));
+        const size_t o_rec = off; off += up(n * sizeof(EnvRec));
         const size_t o_tot = off; off += up(n_total_slots(n_envs) * sizeof(Totals));
         const size_t o_time = off; off += (kind == RMAV_REINMAV) ? up(n * sizeof(double)) : 0;
         const size_t o_er = off; off += tr ? up(n * sizeof(float)) : 0;
         const size_t o_lr = off; off += tr ? up(n * sizeof(float)) : 0;
-        const size_t o_el = off; off += tr ? up(n * sizeof(int32_t)) : 0;
-        const size_t o_ll = off; off += tr ? up(n * sizeof(int32_t)) : 0;
         if (hipMalloc(&h->arena, off) != hipSuccess) {
             (void)hipGetLastError();
             h->arena = nullptr;
@@ -634,25 +656,21 @@ int rmav_create(rmav_handle *out, int kind, int64_t n_envs, int device, uint64_t
         }
         char *b = (char *)h->arena;
         h->state = (float *)(b + o_state);
-        h->sbd = (int32_t *)(b + o_sbd);
-        h->reset_cnt = (uint32_t *)(b + o_rc);
+        h->rec = (EnvRec *)(b + o_rec);
         h->totals = (Totals *)(b + o_tot);
         if (kind == RMAV_REINMAV) h->env_time = (double *)(b + o_time);
         if (tr) {
             h->ep_ret = (float *)(b + o_er);
             h->last_ret = (float *)(b + o_lr);
-            h->ep_start = (uint32_t *)(b + o_el);
-            h->last_len = (int32_t *)(b + o_ll);
         }
     }
-    hipError_t e = hipMemsetAsync(h->sbd, 0xFF, n * sizeof(int32_t), h->stream);  // -1 = None
-    if (e == hipSuccess) e = hipMemsetAsync(h->reset_cnt, 0, n * sizeof(uint32_t), h->stream);
+    // every record: steps_beyond_done = None (-1), no reset drawn yet, the episode clock starts at 0, no finished episode
+    hipLaunchKernelGGL(k_rec_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->rec, EnvRec{-1, 0u, 0u, 0}, -1, (int64_t)n);
+    hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemsetAsync(h->totals, 0, n_total_slots(n_envs) * sizeof(Totals), h->stream);
     if (e == hipSuccess && (flags & RMAV_F_TRACK_EPISODES)) {
         e = hipMemsetAsync(h->ep_ret, 0, n * sizeof(float), h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(h->last_ret, 0, n * sizeof(float), h->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(h->ep_start, 0, n * sizeof(uint32_t), h->stream);   // the clock starts at 0
-        if (e == hipSuccess) e = hipMemsetAsync(h->last_len, 0, n * sizeof(int32_t), h->stream);
     }
     if (e != hipSuccess) {
         free_all(h);
@@ -698,7 +716,7 @@ int rmav_destroy(rmav_handle h) {
 static int move_step_counter(rmav_handle h, uint64_t t) {
     const uint32_t delta = (uint32_t)t - (uint32_t)h->t;
     if (delta != 0u && (h->flags & RMAV_F_TRACK_EPISODES)) {
-        hipLaunchKernelGGL(k_shift_u32, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->ep_start, delta, (int64_t)h->n);
+        hipLaunchKernelGGL(k_shift_ep_start, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->rec, delta, (int64_t)h->n);
         HIP_TRY(hipGetLastError());
     }
     h->t = t;
@@ -709,7 +727,8 @@ int rmav_seed(rmav_handle h, uint64_t seed) {
     CHECK_HANDLE(h);
     h->seed = seed;
     if (int rc = move_step_counter(h, 0)) return rc;
-    HIP_TRY(hipMemsetAsync(h->reset_cnt, 0, (size_t)h->n * sizeof(uint32_t), h->stream));
+    hipLaunchKernelGGL(k_rec_fill, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->rec, EnvRec{0, 0u, 0u, 0}, 1, (int64_t)h->n);   // reset_cnt = 0
+    HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
 
@@ -1164,22 +1183,22 @@ int rmav_set_state(rmav_handle h, const float *in, int mem, int layout) {
 int rmav_get_sbd(rmav_handle h, int32_t *out, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    return copy_out(h, (const int32_t *)h->sbd, out, (size_t)h->n, mem);
+    return rec_field_get(h, 0, reinterpret_cast<uint32_t *>(out), mem);
 }
 int rmav_set_sbd(rmav_handle h, const int32_t *in, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    return copy_in(h, h->sbd, in, (size_t)h->n, mem);
+    return rec_field_set(h, 0, reinterpret_cast<const uint32_t *>(in), mem);
 }
 int rmav_get_reset_counts(rmav_handle h, uint32_t *out, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    return copy_out(h, (const uint32_t *)h->reset_cnt, out, (size_t)h->n, mem);
+    return rec_field_get(h, 1, out, mem);
 }
 int rmav_set_reset_counts(rmav_handle h, const uint32_t *in, int mem) {
     CHECK_HANDLE(h);
     if (int rc = check_mem_layout(mem, RMAV_SOA)) return rc;
-    return copy_in(h, h->reset_cnt, in, (size_t)h->n, mem);
+    return rec_field_set(h, 1, in, mem);
 }
 
 int rmav_get_time(rmav_handle h, double *out, int mem) {
@@ -1242,20 +1261,23 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
     const size_t n = (size_t)h->n;
     const hipMemcpyKind kind = (mem == RMAV_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (last_return) HIP_TRY(hipMemcpyAsync(last_return, h->last_ret, n * sizeof(float), kind, h->stream));
-    if (last_length) HIP_TRY(hipMemcpyAsync(last_length, h->last_len, n * sizeof(int32_t), kind, h->stream));
     if (cur_return) HIP_TRY(hipMemcpyAsync(cur_return, h->ep_ret, n * sizeof(float), kind, h->stream));
-    const uint32_t clock = (uint32_t)h->t;   // running length = episode clock - the episode's start
-    if (cur_length && mem == RMAV_DEVICE) {
-        hipLaunchKernelGGL(k_cur_length, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, cur_length, h->ep_start, clock, (int64_t)n);
+    // lengths live in the per-env records (EnvRec): last_len as it is, the running length = episode clock - the episode's start
+    if (last_length)
+        if (int rc = rec_field_get(h, 3, reinterpret_cast<uint32_t *>(last_length), mem)) return rc;
+    if (cur_length) {
+        const uint32_t clock = (uint32_t)h->t;
+        int32_t *dst = cur_length;
+        if (mem != RMAV_DEVICE) {
+            if (int rc = ensure_scratch(h, n * sizeof(int32_t))) return rc;
+            dst = (int32_t *)h->scratch;
+        }
+        hipLaunchKernelGGL(k_cur_length, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dst, (const EnvRec *)h->rec, clock, (int64_t)n);
         HIP_TRY(hipGetLastError());
-    } else if (cur_length) {
-        HIP_TRY(hipMemcpyAsync(cur_length, h->ep_start, n * sizeof(int32_t), kind, h->stream));
+        if (mem != RMAV_DEVICE)
+            if (int rc = copy_out(h, (const int32_t *)dst, cur_length, n, RMAV_HOST)) return rc;
     }
-    if (mem == RMAV_HOST) {
-        HIP_TRY(hipStreamSynchronize(h->stream));
-        if (cur_length)
-            for (size_t i = 0; i < n; ++i) cur_length[i] = (int32_t)(clock - (uint32_t)cur_length[i]);
-    }
+    if (mem == RMAV_HOST) HIP_TRY(hipStreamSynchronize(h->stream));
     return RMAV_OK;
 }
 
@@ -1525,7 +1547,7 @@ int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out) {
         return rmav_fail(RMAV_ERR_INVALID, "handle was created without RMAV_F_TRACK_EPISODES");
     if (!send_out || cmax < h->n) return rmav_fail(RMAV_ERR_INVALID, "send_out is NULL or cmax < num_envs");
     hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
-                       (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, send_out);
+                       (const float *)h->last_ret, (const EnvRec *)h->rec, h->n, cmax, send_out);
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }
@@ -1656,7 +1678,7 @@ int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total) {
         HIP_TRY(hipGetLastError());
     } else {
         hipLaunchKernelGGL(k_pack_stats, dim3((unsigned)((cmax + 255) / 256)), dim3(256), 0, h->stream,
-                           (const float *)h->last_ret, (const int32_t *)h->last_len, h->n, cmax, c->send[k]);
+                           (const float *)h->last_ret, (const EnvRec *)h->rec, h->n, cmax, c->send[k]);
         HIP_TRY(hipGetLastError());
         if (c->flag) {
             const uint32_t seq = (uint32_t)(c->posts + 1);

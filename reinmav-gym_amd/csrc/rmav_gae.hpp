@@ -179,24 +179,43 @@ __global__ __launch_bounds__(256) void k_pack_policy(const PackSrc src, const in
 }
 
 // running episode lengths for rmav_episode_buffers: clock - ep_start
-__global__ __launch_bounds__(256) void k_cur_length(int32_t *out, const uint32_t *ep_start, uint32_t clock, int64_t n) {
+__global__ __launch_bounds__(256) void k_cur_length(int32_t *out, const EnvRec *rec, uint32_t clock, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int32_t)(clock - ep_start[i]);
+    if (i < n) out[i] = (int32_t)(clock - rec[i].ep_start);
 }
 
-__global__ __launch_bounds__(256) void k_shift_u32(uint32_t *x, uint32_t delta, int64_t n) {
+// the episode clock moved by `delta` (rmav_seed, rmav_set_step_count): every running episode's start moves with it
+__global__ __launch_bounds__(256) void k_shift_ep_start(EnvRec *rec, uint32_t delta, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] += delta;
+    if (i < n) rec[i].ep_start += delta;
+}
+
+// One 32-bit field of the per-env records <-> a dense array (rmav_get_sbd / rmav_set_sbd, the reset counters, last lengths: the
+// accessors of the C ABI; not on any hot path).  field = word index in EnvRec: 0 sbd, 1 reset_cnt, 2 ep_start, 3 last_len.
+__global__ __launch_bounds__(256) void k_rec_get(uint32_t *out, const EnvRec *rec, int field, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = reinterpret_cast<const uint32_t *>(rec)[4 * i + field];
+}
+__global__ __launch_bounds__(256) void k_rec_set(EnvRec *rec, const uint32_t *in, int field, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<uint32_t *>(rec)[4 * i + field] = in[i];
+}
+// field < 0: every record = `value`; otherwise that field of every record = value's
+__global__ __launch_bounds__(256) void k_rec_fill(EnvRec *rec, EnvRec value, int field, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (field < 0) rec[i] = value;
+    else reinterpret_cast<uint32_t *>(rec)[4 * i + field] = reinterpret_cast<const uint32_t *>(&value)[field];
 }
 
 // ---- episode statistics exchange (the path's one collective) ------------------------------------------------
 // send = [2][cmax] int32: returns (bit pattern) then lengths of this rank's `count` envs, zero padded to cmax
-__global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ last_ret, const int32_t *__restrict__ last_len,
+__global__ __launch_bounds__(256) void k_pack_stats(const float *__restrict__ last_ret, const EnvRec *__restrict__ rec,
                                                     int64_t count, int64_t cmax, int32_t *__restrict__ send) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cmax) return;
     send[i] = i < count ? __float_as_int(last_ret[i]) : 0;
-    send[cmax + i] = i < count ? last_len[i] : 0;
+    send[cmax + i] = i < count ? rec[i].last_len : 0;
 }
 // one thread: publish `seq` in a signal word another HIP stream waits on with hipStreamWaitValue32 (the kernel boundary
 // in front of this launch has released the payload).  Folding this into k_pack_stats - every workgroup releases and takes

@@ -47,11 +47,8 @@ struct rmav_env_s {
     int64_t chunk;  // > 0 only inside rmav_rollout_chunked: the call's trajectory arrays are chunk-major [n_chunks][T][dim][chunk]
     // device-resident env data
     float *state;
-    int32_t *sbd;
-    uint32_t *reset_cnt;
+    rmav::EnvRec *rec;   // per-env termination record {sbd, reset_cnt, ep_start, last_len} (rmav_kernels.hpp: EnvRec, ep_clock0)
     float *ep_ret, *last_ret;
-    uint32_t *ep_start;  // (uint32_t)t at the start of each env's running episode (rmav_kernels.hpp: ep_clock0)
-    int32_t *last_len;
     rmav::Totals *totals;
     double *env_time;  // RMAV_REINMAV only
     void *arena;       // ONE allocation behind all of the arrays above (see rmav_create)

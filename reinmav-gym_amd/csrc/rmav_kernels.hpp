@@ -4,9 +4,11 @@
 //   state      f32 [nS][N]   struct-of-arrays, updated in place; lane i of a wavefront owns env i,
 //                            so every load/store of a component is one fully coalesced 256-byte
 //                            wave transaction
-//   sbd        i32 [N]       steps_beyond_done (-1 = None); touched only by lanes whose env is done
-//   reset_cnt  u32 [N]       resets drawn so far (RNG counter); touched only on reset
-//   ep_ret/ep_len, last_ret/last_len   optional Monitor-style episode accumulators
+//   rec        EnvRec [N]    ONE 16-byte record per env of what a lane needs only when its episode ENDS: steps_beyond_done
+//                            (-1 = None), resets drawn so far (the RNG counter), the episode clock at the running episode's
+//                            start, the last finished episode's length - one sector in, one out per termination (round 6;
+//                            four separate arrays before: three scattered sectors in, four out)
+//   ep_ret, last_ret   f32 [N]  running return (in / out every step when tracking), last finished episode's return
 //   totals     {u64,f64,u64} [ceil(N/64)]  per-wavefront partial sums of finished episodes
 //   env_time   f64 [N]       RMAV_REINMAV only: each env's clock
 //   pe[3]      f32 [N]       optional per-env mass / load mass / tether length (domain randomisation)
@@ -116,6 +118,22 @@ template <int K, int MODE> constexpr int split_words_per_pair() {
 enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u, F_ROLE_SWAP = 16u };
 
 
+// What a lane needs only when its env's episode ends, as ONE 16-byte record per env (b128 / b96 accesses):
+//   sbd        steps_beyond_done, -1 = None (quadrotor3d.py:68,112-122)
+//   reset_cnt  resets drawn so far = the Philox counter of the next fresh state
+//   ep_start   value of the handle's episode clock when the running episode began: length = clock - ep_start (ep_clock0 below)
+//   last_len   length of the most recently finished episode (0: none yet); its return is last_ret[i]
+// Round 6 (profiles/r06/step_shape_*.md: a kernel of k_step's memory shape, 1.3 % of the lanes ending an episode): as four
+// arrays a termination costs three scattered 32-byte sectors in and four partial sectors out (+ the return); as one record
+// one sector in, one 16-byte store out - 1 048 576 envs 24.0 -> 21.6 us, 262 144 envs 5.8 (eager dword loads) -> 5.4.
+struct alignas(16) EnvRec {
+    int32_t sbd;
+    uint32_t reset_cnt;
+    uint32_t ep_start;
+    int32_t last_len;
+};
+static_assert(sizeof(EnvRec) == 16, "one b128 access per record");
+
 struct Totals {
     unsigned long long episodes;
     double return_sum;
@@ -132,12 +150,9 @@ struct RolloutArgs {
     float *obs_out;
     float *rew_out;
     uint8_t *done_out;
-    int32_t *sbd;
-    uint32_t *reset_cnt;
+    EnvRec *rec;            // per-env termination record {sbd, reset_cnt, ep_start, last_len} (see EnvRec)
     float *ep_ret;
-    uint32_t *ep_start;     // value of the handle's episode clock when the env's running episode began: length = clock - ep_start
     float *last_ret;
-    int32_t *last_len;
     Totals *totals;
     uint64_t seed;
     uint64_t env_base;
@@ -217,6 +232,21 @@ __device__ __forceinline__ void buf_st(rsrc_t r, uint32_t voff, uint32_t soff, f
 __device__ __forceinline__ void buf_st_i32(rsrc_t r, uint32_t voff, uint32_t soff, int32_t v) {
     __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, r, voff, soff, 0);
 }
+// EnvRec accesses: the lane's record sits at byte offset 16 * env (N <= 2^25: fits 32 bits).  b96 = {sbd, reset_cnt, ep_start},
+// b64 = {sbd, reset_cnt}; last_len (offset 12) is written on its own by the kernels that keep the rest in registers.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3_t __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4_t rec_ld4(rsrc_t r, uint32_t env) { return __builtin_amdgcn_raw_buffer_load_b128(r, env * 16u, 0, 0); }
+__device__ __forceinline__ u32x3_t rec_ld3(rsrc_t r, uint32_t env) { return __builtin_amdgcn_raw_buffer_load_b96(r, env * 16u, 0, 0); }
+__device__ __forceinline__ u32x2_t rec_ld2(rsrc_t r, uint32_t env) { return __builtin_amdgcn_raw_buffer_load_b64(r, env * 16u, 0, 0); }
+__device__ __forceinline__ void rec_st4(rsrc_t r, uint32_t env, u32x4_t v) { __builtin_amdgcn_raw_buffer_store_b128(v, r, env * 16u, 0, 0); }
+__device__ __forceinline__ void rec_st3(rsrc_t r, uint32_t env, u32x3_t v) { __builtin_amdgcn_raw_buffer_store_b96(v, r, env * 16u, 0, 0); }
+__device__ __forceinline__ void rec_st2(rsrc_t r, uint32_t env, u32x2_t v) { __builtin_amdgcn_raw_buffer_store_b64(v, r, env * 16u, 0, 0); }
+// one field (word w of the record) on its own: for kernels at their register limit, where a 2- / 3-register tuple would spill
+__device__ __forceinline__ uint32_t rec_ld_word(rsrc_t r, uint32_t env, int w) { return __builtin_amdgcn_raw_buffer_load_b32(r, env * 16u, 4 * w, 0); }
+__device__ __forceinline__ void rec_st_word(rsrc_t r, uint32_t env, int w, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, env * 16u, 4 * w, 0); }
+__device__ __forceinline__ void rec_st_last_len(rsrc_t r, uint32_t env, int32_t v) { __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, r, env * 16u, 12, 0); }
 
 // Cache policy of the SoA trajectory stores - a template parameter because the policy bits are instruction
 // immediates (a wave-uniform runtime switch around three copies of the stores measured 9 % SLOWER than no
@@ -759,16 +789,30 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         for (int c = 0; c < NS; ++c) s[c] = buf_ld(r_state, off, (uint32_t)c * col);
         float er = 0.0f;
         int32_t el = 0;
-        if (track) {
-            er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-            el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
-        }
         // steps_beyond_done and the reset counter ride in registers for the whole launch: loading them
         // on demand (only lanes that terminate need them) would put one or two dependent HBM round
         // trips into every step of every wavefront that has a finishing lane (~57 % of them at the
-        // 1.3 %/step termination rate of random actions).
-        int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-        uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
+        // 1.3 %/step termination rate of random actions).  One access of the env's record (EnvRec) brings both, and the
+        // episode's start when tracking.
+        const rsrc_t r_rec = make_rsrc(a.rec);
+        int32_t sb;
+        uint32_t rc;
+        constexpr bool REC_WORDS = is_policy(MODE);   // the one-wavefront actors sit at their register limit: word accesses, no tuples
+        if (track) er = buf_ld(make_rsrc(a.ep_ret), off, 0);
+        if constexpr (REC_WORDS) {
+            sb = (int32_t)rec_ld_word(r_rec, li, 0);
+            rc = rec_ld_word(r_rec, li, 1);
+            if (track) el = (int32_t)(ep_clock0(a) - rec_ld_word(r_rec, li, 2));
+        } else if (track) {
+            const u32x3_t q = rec_ld3(r_rec, li);
+            sb = (int32_t)q.x;
+            rc = q.y;
+            el = (int32_t)(ep_clock0(a) - q.z);
+        } else {
+            const u32x2_t q = rec_ld2(r_rec, li);
+            sb = (int32_t)q.x;
+            rc = q.y;
+        }
         // (written back unconditionally at the end of the launch: neither copies of the loaded values - two registers of the
         // step loop - nor per-lane dirty masks - four scalar instructions per step - for 8 B per env and LAUNCH)
         const uint64_t env_id = a.env_base + (uint64_t)li;
@@ -1014,7 +1058,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 if (__ballot(done) != 0) {
                     if (track && done) {
                         buf_st(make_rsrc(a.last_ret), off, 0, er);
-                        buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                        rec_st_last_len(make_rsrc(a.rec), li, el);
                         if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
                             fin_n += 1;
                             fin_len += (unsigned int)el;
@@ -1054,7 +1098,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                     el += 1;
                     if (done) {
                         buf_st(make_rsrc(a.last_ret), off, 0, er);
-                        buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                        rec_st_last_len(make_rsrc(a.rec), li, el);
                         if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
                             fin_n += 1;
                             fin_len += (unsigned int)el;
@@ -1181,13 +1225,17 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 for (int c = 0; c < NA; ++c) buf_st(rc2, off, (uint32_t)c * col, a2[c]);
             }
         }
-        if (track) {
-            buf_st(make_rsrc(a.ep_ret), off, 0, er);
-            buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
-        }
         if constexpr (K == REINMAV) a.env_time[li] = tenv;
-        buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-        buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
+        if (track) buf_st(make_rsrc(a.ep_ret), off, 0, er);
+        if constexpr (is_policy(MODE)) {
+            rec_st_word(make_rsrc(a.rec), li, 0, (uint32_t)sb);
+            rec_st_word(make_rsrc(a.rec), li, 1, rc);
+            if (track) rec_st_word(make_rsrc(a.rec), li, 2, ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el);
+        } else if (track) {
+            rec_st3(make_rsrc(a.rec), li, u32x3_t{(uint32_t)sb, rc, ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el});
+        } else {
+            rec_st2(make_rsrc(a.rec), li, u32x2_t{(uint32_t)sb, rc});
+        }
     }
 
     if (track) {
@@ -1226,7 +1274,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (valid && !(HALF && (threadIdx.x & 32u))) {
             const float lr = a.last_ret[li];
-            const int32_t ll = a.last_len[li];
+            const int32_t ll = a.rec[li].last_len;
             __hip_atomic_store(a.xsend + li, __builtin_bit_cast(int32_t, lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.xsend + a.xcmax + li, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1354,12 +1402,16 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     if (track) er = buf_ld(make_rsrc(a.ep_ret), off, 0);
     // needed only by lanes whose env terminates in this step: steps_beyond_done (the terminal reward), the reset counter
     // (the Philox counter of the fresh state) and the episode's start (its length)
+    // - ONE 16-byte record per env (EnvRec): one b128 load, and one b128 store when the episode ends
     int32_t sb = -1;
     uint32_t rc = 0, es = 0;
+    int32_t ll = 0;   // the record's last_len: rewritten with the record (kept when the handle does not track episodes)
     if constexpr (!LAZY) {
-        sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-        rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
-        if (track) es = (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0);
+        const u32x4_t q = rec_ld4(make_rsrc(a.rec), li);
+        sb = (int32_t)q.x;
+        rc = q.y;
+        es = q.z;
+        ll = (int32_t)q.w;
     }
     if constexpr (kVectorTotals) if (track) {
         const Totals *tp = a.totals + (gi >> 6);
@@ -1380,10 +1432,12 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     bool done;
     Env<K>::step(s, act, pl, dist, done);
     if constexpr (LAZY) {
-        if (done) {   // only the finishing lanes fetch (one 32-byte sector each instead of the wavefront's 256 bytes)
-            sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-            rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
-            if (track) es = (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0);
+        if (done) {   // only the finishing lanes fetch: ONE 32-byte sector each
+            const u32x4_t q = rec_ld4(make_rsrc(a.rec), li);
+            sb = (int32_t)q.x;
+            rc = q.y;
+            es = q.z;
+            ll = (int32_t)q.w;
         }
     }
     // reward / steps_beyond_done machine  (quadrotor3d.py:112-122 and siblings)
@@ -1405,8 +1459,8 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
                 const uint32_t clk = ep_clock0(a) + 1u;       // the episode clock after this step
                 const int32_t el = (int32_t)(clk - es);       // steps of the episode that ends here
                 buf_st(make_rsrc(a.last_ret), off, 0, er);
-                buf_st_i32(make_rsrc(a.last_len), off, 0, el);
-                buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)clk);   // the next episode starts now
+                ll = el;
+                es = clk;                                     // the next episode starts now
                 fin = true;
                 fin_ret = er;
                 fin_len = el;
@@ -1414,10 +1468,8 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
             }
             buf_st_aux<AUX>(make_rsrc(a.ep_ret), off, 0, er);
         }
-        if (done) {
-            buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-            if (auto_reset) buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)(rc + 1u));
-        }
+        if (done)   // the whole record in one 16-byte store
+            rec_st4(make_rsrc(a.rec), li, u32x4_t{(uint32_t)sb, auto_reset ? rc + 1u : rc, es, (uint32_t)ll});
     }
     if (auto_reset)   // wave-uniform; every lane takes part
         reset_state_wave<K>(a.seed, a.env_base + (uint64_t)(gi - (threadIdx.x & 63u)), rc, done && valid, s);
@@ -1481,14 +1533,15 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
 
 // reset() of every env
 template <int K>
-__global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint32_t *reset_cnt,
-                                                  float *ep_ret, uint32_t *ep_start, uint32_t ep_clock, float *obs_out,
+__global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, EnvRec *rec,
+                                                  float *ep_ret, uint32_t ep_clock, float *obs_out,
                                                   uint64_t seed, uint64_t env_base, uint32_t flags) {
     constexpr int NS = Dims<K>::NS;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float s[NS];
-    const uint32_t rc = reset_cnt[i];
+    EnvRec q = rec[i];
+    const uint32_t rc = q.reset_cnt;
     if constexpr (K == REINMAV) {   // ReinmavEnv.reset() returns the current state unchanged (reinmav_env.py:348-351)
 #pragma unroll
         for (int c = 0; c < NS; ++c) s[c] = state[(int64_t)c * n + i];
@@ -1497,11 +1550,12 @@ __global__ __launch_bounds__(kBlock) void k_reset(float *state, int64_t n, uint3
 #pragma unroll
         for (int c = 0; c < NS; ++c) state[(int64_t)c * n + i] = s[c];
     }
-    reset_cnt[i] = rc + 1;
+    q.reset_cnt = rc + 1;
     if (flags & F_TRACK) {
         ep_ret[i] = 0.0f;
-        ep_start[i] = ep_clock;   // running length 0
+        q.ep_start = ep_clock;   // running length 0
     }
+    rec[i] = q;                  // (steps_beyond_done is NOT cleared: quadrotor3d.py:182-185 does not)
     if (obs_out) {
         if (flags & F_AOS) {
 #pragma unroll

@@ -323,12 +323,19 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     float fin_ret = 0.0f;
     float er = 0.0f;
     int32_t el = 0;
+    int32_t sb;   // the env's record (EnvRec): steps_beyond_done, reset counter and - when tracking - the episode's start in ONE access
+    uint32_t rc;
     if (track) {
         er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-        el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
+        const u32x3_t q = rec_ld3(make_rsrc(a.rec), li);
+        sb = (int32_t)q.x;
+        rc = q.y;
+        el = (int32_t)(ep_clock0(a) - q.z);
+    } else {
+        const u32x2_t q = rec_ld2(make_rsrc(a.rec), li);
+        sb = (int32_t)q.x;
+        rc = q.y;
     }
-    int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-    uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
     typename Env<K>::P pl = p_shared;
     if constexpr (K != REINMAV) {
         if (a.pe[0] || a.pe[1] || a.pe[2]) {
@@ -391,7 +398,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
             el += 1;
             if (done) {
                 buf_st(make_rsrc(a.last_ret), off, 0, er);
-                buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                rec_st_last_len(make_rsrc(a.rec), li, el);
                 if (valid) {
                     fin_n += 1;
                     fin_len += (unsigned int)el;
@@ -426,13 +433,13 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+    if constexpr (K == REINMAV) a.env_time[li] = tenv;
     if (track) {
         buf_st(make_rsrc(a.ep_ret), off, 0, er);
-        buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
+        rec_st3(make_rsrc(a.rec), li, u32x3_t{(uint32_t)sb, rc, ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el});
+    } else {
+        rec_st2(make_rsrc(a.rec), li, u32x2_t{(uint32_t)sb, rc});
     }
-    if constexpr (K == REINMAV) a.env_time[li] = tenv;
-    buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-    buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     if (track && __ballot(fin_n != 0) != 0) {   // episode totals: this wavefront's slot (see k_rollout)
         Totals *slot = a.totals + (gi >> 6);
         const unsigned int wn = wave_sum_x(fin_n);
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair(const R
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (valid) {
             const float lr = a.last_ret[li];
-            const int32_t ll = a.last_len[li];
+            const int32_t ll = a.rec[li].last_len;
             __hip_atomic_store(a.xsend + li, __builtin_bit_cast(int32_t, lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.xsend + a.xcmax + li, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -658,12 +665,19 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
     float fin_ret = 0.0f;
     float er = 0.0f;
     int32_t el = 0;
+    int32_t sb;   // the env's record (EnvRec): steps_beyond_done, reset counter and - when tracking - the episode's start in ONE access
+    uint32_t rc;
     if (track) {
         er = buf_ld(make_rsrc(a.ep_ret), off, 0);
-        el = (int32_t)(ep_clock0(a) - (uint32_t)buf_ld_i32(make_rsrc(a.ep_start), off, 0));
+        const u32x3_t q = rec_ld3(make_rsrc(a.rec), li);
+        sb = (int32_t)q.x;
+        rc = q.y;
+        el = (int32_t)(ep_clock0(a) - q.z);
+    } else {
+        const u32x2_t q = rec_ld2(make_rsrc(a.rec), li);
+        sb = (int32_t)q.x;
+        rc = q.y;
     }
-    int32_t sb = buf_ld_i32(make_rsrc(a.sbd), off, 0);
-    uint32_t rc = (uint32_t)buf_ld_i32(make_rsrc(a.reset_cnt), off, 0);
     typename Env<K>::P pl = p_shared;
     if constexpr (K != REINMAV) {
         if (a.pe[0] || a.pe[1] || a.pe[2]) {
@@ -741,7 +755,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
             el += 1;
             if (done) {
                 buf_st(make_rsrc(a.last_ret), off, 0, er);
-                buf_st_i32(make_rsrc(a.last_len), off, 0, el);
+                rec_st_last_len(make_rsrc(a.rec), li, el);
                 if (valid) {
                     fin_n += 1;
                     fin_len += (unsigned int)el;
@@ -780,13 +794,13 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
     }
 #pragma unroll
     for (int c = 0; c < NS; ++c) buf_st(r_state, off, (uint32_t)c * col, s[c]);
+    if constexpr (K == REINMAV) a.env_time[li] = tenv;
     if (track) {
         buf_st(make_rsrc(a.ep_ret), off, 0, er);
-        buf_st_i32(make_rsrc(a.ep_start), off, 0, (int32_t)(ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el));
+        rec_st3(make_rsrc(a.rec), li, u32x3_t{(uint32_t)sb, rc, ep_clock0(a) + (uint32_t)a.n_steps - (uint32_t)el});
+    } else {
+        rec_st2(make_rsrc(a.rec), li, u32x2_t{(uint32_t)sb, rc});
     }
-    if constexpr (K == REINMAV) a.env_time[li] = tenv;
-    buf_st_i32(make_rsrc(a.sbd), off, 0, sb);
-    buf_st_i32(make_rsrc(a.reset_cnt), off, 0, (int32_t)rc);
     if (track && __ballot(fin_n != 0) != 0) {
         Totals *slot = a.totals + (gi >> 6);
         const unsigned int wn = wave_sum_x(fin_n);
@@ -802,7 +816,7 @@ __global__ __launch_bounds__(128 * kPairGroupMax, 2) void k_rollout_pair_shared(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (valid) {
             const float lr = a.last_ret[li];
-            const int32_t ll = a.last_len[li];
+            const int32_t ll = a.rec[li].last_len;
             __hip_atomic_store(a.xsend + li, __builtin_bit_cast(int32_t, lr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(a.xsend + a.xcmax + li, ll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
