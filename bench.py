@@ -44,8 +44,10 @@ Output: the LAST stdout line is ONE compact JSON object (< 4 KB: the contract ke
 secondary leg in full, device state, the CPU thread scan, calibration - goes to ``--detail`` (default
 ``gpurun_out/bench_detail.json``), named by the line's ``detail`` key; nothing else is printed to stdout, and stderr
 stays quiet unless something fails.  (Round 4's single 22 KB line could not be recovered from the driver's 8 KB tail.)
-Default ``--secondary`` = the per-step kernel at three batch sizes + the sustained stretch (~4 s); ``--secondary all``
-adds the other BASELINE configs and the policy-in-kernel rollouts (~25 s).
+Default ``--secondary`` = the per-step kernel at three batch sizes, BASELINE configs[2]'s per-GPU shard (plain and chunk-major
+trajectories) and configs[3] (~1 s each), and the sustained stretch (11 s of the headline launches, so that an outside GPU-busy
+sampler cannot miss it); with the 10 s + 3 s CPU baselines the default run takes ~30 s.  ``--secondary all`` adds the
+policy-in-kernel rollouts, ReinmavEnv, the gym-shaped env and the VecEnv (~25 s more).
 """
 from __future__ import annotations
 
@@ -287,7 +289,7 @@ def rollout_leg(g, torch, dev, kind: str, n: int, chunk: int, K: int, W: int, la
     del ring
     torch.cuda.empty_cache()
     b = fused_bytes_per_launch(n, chunk, nS, nA) + (12 * n if per_env_params else 0)
-    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:soa" + (":pe" if per_env_params else "") + (":chunked" if chunk_major else ""))
+    tr, src = lookup_traffic(f"{kind}:rollout:{chunk}:{n}:ring:random:" + ("chunked" if chunk_major else "soa") + (":pe" if per_env_params else ""))
     out = {"workload": f"{label}: {ENV_ID[kind]}, {n} envs, random actions, auto-reset, episode tracking; {chunk}-step fused launches "
                        f"into a ring of {R} trajectory buffer sets ({R * per_set / 1e9:.2f} GB: cold stores)" +
                        (f"; CHUNK-MAJOR trajectory arrays [{nc}][{chunk}][dim][{ce}], one launch per chunk (rmav_rollout_chunked)" if chunk_major else "") +
@@ -417,7 +419,9 @@ def main():
     ap.add_argument("--chunk", type=int, default=64,
                     help="env-steps per launch in rollout mode (64 amortises the ~4.5 us fixed cost of a launch; "
                          "see profiles/*/sweep_kinds_sizes.md for 8..128)")
-    ap.add_argument("--layout", default="soa", choices=["soa", "aos"], help="trajectory layout in rollout mode")
+    ap.add_argument("--layout", default="auto", choices=["auto", "soa", "aos", "chunked"],
+                    help="trajectory layout in rollout mode; auto = the library's recommendation (rmav_chunk_envs): chunk-major [C][T][dim][65536] "
+                         "for quadrotor3d beyond 65 536 envs (a learner flattens the samples anyway), plain feature-major [T][dim][N] otherwise")
     ap.add_argument("--in-place", action="store_true", help="rollout mode: rewrite ONE trajectory buffer set (cache-assisted)")
     ap.add_argument("--ring", type=int, default=0, help="rollout mode: number of trajectory buffer sets (0 = >= 5 and > 1.5 GB)")
     ap.add_argument("--prewarm-ms", type=float, default=40.0,
@@ -429,7 +433,10 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the other modes' short measurements")
     ap.add_argument("--tune", default="", help="comma list of key=value overrides of the launch heuristics (rmav_set_tuning), "
                                                "e.g. split=0,store_policy=2")
-    ap.add_argument("--secondary", default="step,sustained,cpu_mt",
+    ap.add_argument("--sustained-seconds", type=float, default=11.0,
+                    help="length of the `sustained` leg: the headline launches back to back, long enough for an outside GPU-busy sampler "
+                         "with a 5 s period to see at least two busy samples")
+    ap.add_argument("--secondary", default="step,sustained,cpu_mt,c3_shard,c4",
                     help="comma list of the other measurements (single process only): step (k_step at 65 536 / 262 144 / 1 048 576 envs), "
                          "sustained, in_place, c3_shard, c4, c4_pe, reinmav, gym1, vecenv, policy, cpu_mt (OpenMP CPU baseline), cpu_py; "
                          "'all' = every one of them (~25 s more)")
@@ -484,6 +491,9 @@ def main():
         tune = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv}
         if tune:
             env.set_tuning(**tune)
+        chunk_envs = int(A.lib().rmav_chunk_envs(env._h))
+        if args.layout == "auto":   # what BatchedQuadrotor.rollout(layout="chunked") gives: one chunk = the plain layout
+            args.layout = "chunked" if (chunk_envs < n and args.actions != "buffer" and args.mode == "rollout") else "soa"
         gloo = use_dist and dist.get_backend() == "gloo"
         exchange, exchange_kind, native_abandoned, comm_info = None, None, False, None
         if use_dist:
@@ -540,15 +550,19 @@ def main():
         def make_runner(mode, chunk, in_place=False):
             """Returns (run(k): enqueue k launches, env-steps per env per launch, buffer sets)."""
             if mode == "rollout":
-                shp = (lambda d: (chunk, d, n)) if args.layout == "soa" else (lambda d: (chunk, n, d))
+                chunked = args.layout == "chunked"
+                ce = min(chunk_envs, (n + 63) // 64 * 64)
+                ncz = -(-n // ce)
+                shp = ((lambda d: (ncz, chunk, d, ce)) if chunked else (lambda d: (chunk, d, n)) if args.layout == "soa" else (lambda d: (chunk, n, d)))
+                shp1 = (ncz, chunk, ce) if chunked else (chunk, n)
                 R = ring_size(chunk, in_place)
                 # zero-filled at set-up so that every buffer set is mapped before the warm-up (a short --warmup would
                 # otherwise first-touch part of the ring inside the timed region)
                 ring = [{
                     "actions": torch.zeros(shp(nA), dtype=torch.float32, device=dev),
                     "obs": torch.zeros(shp(nS), dtype=torch.float32, device=dev),
-                    "rew": torch.zeros((chunk, n), dtype=torch.float32, device=dev),
-                    "done": torch.zeros((chunk, n), dtype=torch.uint8, device=dev),
+                    "rew": torch.zeros(shp1, dtype=torch.float32, device=dev),
+                    "done": torch.zeros(shp1, dtype=torch.uint8, device=dev),
                 } for _ in range(R)]
                 it = [0]
                 if args.actions == "buffer":   # the ring's action buffers are the INPUT: filled once, read every launch
@@ -633,6 +647,7 @@ def main():
         other = {}
         single = not use_dist and not args.no_secondary
         sec = set(args.secondary.split(",")) if single else set()
+        all_legs = "all" in sec
         if "all" in sec:
             sec = {"in_place", "step", "c3_shard", "c4", "c4_pe", "reinmav", "gym1", "vecenv", "policy", "sustained", "cpu_mt", "cpu_py"}
         if "step" in sec or "in_place" in sec:
@@ -657,7 +672,7 @@ def main():
                                                             "BASELINE configs[2]'s per-GPU shard, chunk-major trajectories", chunk_major=True)
                 if "c4" in sec:
                     other["c4"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80, "BASELINE configs[3] (C4)",
-                                              cpu_seconds=min(3.0, args.cpu_seconds))
+                                              cpu_seconds=min(3.0, args.cpu_seconds) if all_legs else 0.0)   # (its own CPU side-by-side: --secondary all)
                 if "c4_pe" in sec:
                     other["c4_per_env_params"] = rollout_leg(g, torch, dev, "quad3d_sl", 262144, args.chunk, 300, 80,
                                                              "BASELINE configs[3] (C4) with per-env constants", per_env_params=True)
@@ -676,13 +691,14 @@ def main():
                                                                prewarm_ms=args.prewarm_ms)
         device_state = sampler.summary()
         if single and "sustained" in sec and args.mode == "rollout":
-            # >= 2.5 s of the headline launches back to back (outside the K timed ones): a stretch long enough for clocks and the
-            # package power limit to settle, and for an outside busy sampler to see the GPU at work at all - the K = 20 launches
-            # of the driver's default command are 0.9 ms of a ~20 s process
-            k_s = max(args.steps, int(2.5 / max(1e-6, kernel_ms * 1e-3)))
+            # --sustained-seconds (11 s) of the headline launches back to back (outside the K timed ones): a stretch long enough for
+            # clocks and the package power limit to settle, and for an outside busy sampler with a 5 s period to see the GPU at work
+            # in at least two samples - the K = 20 launches of the driver's default command are 0.9 ms of a ~30 s process (round 5's
+            # 2.5 s stretch was missed by all four of the driver's samples)
+            k_s = max(args.steps, int(args.sustained_seconds / max(1e-6, kernel_ms * 1e-3)))
             with DeviceSampler(dev.index or 0) as sampler2:
                 w_s, kms_s, pl_s, _, _ = measure(args.mode, args.chunk, k_s, 0, args.in_place, prewarm_ms=0.0)
-            other["sustained"] = {"workload": "the headline launches, back to back for >= 2.5 s", "seconds": w_s, "launches": k_s,
+            other["sustained"] = {"workload": f"the headline launches, back to back for >= {args.sustained_seconds:g} s", "seconds": w_s, "launches": k_s,
                                   "value": n_total * pl_s * k_s / w_s, "unit": "env-steps/s", "ms_per_launch_hip_events": kms_s,
                                   "roofline_frac": fused_bytes_per_launch(n, pl_s, nS, nA) / (kms_s * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                   "device_state": sampler2.summary()}
@@ -846,7 +862,7 @@ def main():
                 # min(affinity mask, cgroup quota), and at the physical-core count when SMT doubles it; >= 3 s each
                 scan = {}
                 for k in sorted({hc["usable"], hc["usable_physical"]}):
-                    scan[k] = cpu_baseline(kind, n, args.chunk, lo, hi, max(3.0, min(5.0, args.cpu_seconds)), threads=k)
+                    scan[k] = cpu_baseline(kind, n, args.chunk, lo, hi, 3.0, threads=k)
                 best = max(scan.values(), key=lambda r: r["value"])
                 best = dict(best, cores_available=hc["usable"], physical_cores=hc["physical_cores_in_affinity"],
                             cgroup_quota_cpus=hc["cgroup_quota_cpus"], speedup_over_1_thread=best["value"] / cb["value"],
@@ -871,6 +887,8 @@ def main():
         legs = leg_rows(other)
         if legs:
             line["legs"] = legs
+        if "sustained" in other:   # the robust figure beside the K timed launches: the same launches over --sustained-seconds
+            line["value_sustained"] = float(f"{other['sustained']['value']:.5g}")
         dpath = args.detail
         if dpath is None:
             dpath = os.path.join(ROOT, "gpurun_out", "bench_detail.json" if world == 1 else f"bench_detail_n{world}.json")

@@ -223,6 +223,10 @@ __device__ __forceinline__ rsrc_t make_rsrc_bounded(const void *p, uint32_t byte
 __device__ __forceinline__ float buf_ld(rsrc_t r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// read-once data (a caller's action buffer): non-temporal
+__device__ __forceinline__ float buf_ld_nt(rsrc_t r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 2));
+}
 __device__ __forceinline__ int32_t buf_ld_i32(rsrc_t r, uint32_t voff, uint32_t soff) {
     return (int32_t)__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0);
 }
@@ -1396,7 +1400,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     } else {
         const rsrc_t r = make_rsrc(a.act_in);
 #pragma unroll
-        for (int c = 0; c < NA; ++c) act[c] = buf_ld(r, off, (uint32_t)c * tcol);
+        for (int c = 0; c < NA; ++c) act[c] = LAZY ? buf_ld_nt(r, off, (uint32_t)c * tcol) : buf_ld(r, off, (uint32_t)c * tcol);   // big batches: read-once, non-temporal (1 048 576 envs -2 %)
     }
     float er = 0.0f;
     if (track) er = buf_ld(make_rsrc(a.ep_ret), off, 0);
@@ -1431,6 +1435,34 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     float dist = 0.0f;
     bool done;
     Env<K>::step(s, act, pl, dist, done);
+    // Where and how the step's outputs are stored (same values on both paths): reward, done, running return
+    auto store_scalars = [&](float r_, bool done_, float er_) {
+        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out), off, 0, r_);
+        if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done_ ? 1 : 0), make_rsrc(a.done_out), li, 0, AUX);
+        if (track) buf_st_aux<AUX>(make_rsrc(a.ep_ret), off, 0, er_);
+    };
+    // ... the state in place, and the obs copy when the caller wants one
+    // (Batch-major obs through an LDS transpose - as the fused kernels do for big launches - was built and measured here in
+    // round 3: QuadrotorVecEnv.step at 65 536 envs 4.91-5.02 us with it, 4.99-5.01 without; not kept.)
+    auto store_state = [&]() {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(r_state, off, (uint32_t)c * col, s[c]);
+        if (a.obs_out) {
+            if (aos) {
+                float *dst = a.obs_out + (int64_t)li * NS;
+#pragma unroll
+                for (int c = 0; c < NS; ++c) dst[c] = s[c];
+            } else {
+                const rsrc_t ro = make_rsrc(a.obs_out);
+#pragma unroll
+                for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * tcol, s[c]);
+            }
+        }
+    };
+    // (Round 6, measured and NOT kept - profiles/r06/step_early_stores_ab.md: storing the outputs of the lanes whose env goes on
+    // right here, under the execution mask, ahead of the finishing lanes' record round trip and reset draw, and the finishing
+    // lanes' afterwards.  Every store of the 57 % of wavefronts with a finishing lane then leaves as two partial-line pieces:
+    // 1 048 576 envs 23.0 -> 25.9 us, 4 194 304 envs 85.1 -> 99.9.)
     if constexpr (LAZY) {
         if (done) {   // only the finishing lanes fetch: ONE 32-byte sector each
             const u32x4_t q = rec_ld4(make_rsrc(a.rec), li);
@@ -1451,8 +1483,6 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
     int32_t fin_len = 0;
     // everything that does not need the reset state goes out first
     if (valid) {
-        if (a.rew_out) buf_st_aux<AUX>(make_rsrc(a.rew_out), off, 0, r);
-        if (a.done_out) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(done ? 1 : 0), make_rsrc(a.done_out), li, 0, AUX);
         if (track) {
             er += r;
             if (done) {
@@ -1466,30 +1496,14 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
                 fin_len = el;
                 er = 0.0f;
             }
-            buf_st_aux<AUX>(make_rsrc(a.ep_ret), off, 0, er);
         }
+        store_scalars(r, done, er);
         if (done)   // the whole record in one 16-byte store
             rec_st4(make_rsrc(a.rec), li, u32x4_t{(uint32_t)sb, auto_reset ? rc + 1u : rc, es, (uint32_t)ll});
     }
     if (auto_reset)   // wave-uniform; every lane takes part
         reset_state_wave<K>(a.seed, a.env_base + (uint64_t)(gi - (threadIdx.x & 63u)), rc, done && valid, s);
-    if (valid) {
-#pragma unroll
-        for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(r_state, off, (uint32_t)c * col, s[c]);
-    }
-    // (Batch-major obs through an LDS transpose - as the fused kernels do for big launches - was built and measured here in
-    // round 3: QuadrotorVecEnv.step at 65 536 envs 4.91-5.02 us with it, 4.99-5.01 without; not kept.)
-    if (valid && a.obs_out) {
-        if (aos) {
-            float *dst = a.obs_out + (int64_t)li * NS;
-#pragma unroll
-            for (int c = 0; c < NS; ++c) dst[c] = s[c];
-        } else {
-            const rsrc_t ro = make_rsrc(a.obs_out);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) buf_st_aux<AUX>(ro, off, (uint32_t)c * tcol, s[c]);
-        }
-    }
+    if (valid) store_state();
     if constexpr (CTRL) {   // control() of the state this launch leaves behind
         float a2[NA];
         env_control<K>(s, pcl, a2);

@@ -264,7 +264,17 @@ class BatchedQuadrotor:
         size that is not a multiple of 16 keeps the fast store path (include/rmav.h: rmav_rollout_pitched; 65 599 envs: 66.6 -> 46.3 us
         per 64-step launch).  Opt-in, because such views are not contiguous (``.view()`` on them fails).  They can be handed back
         as ``out=`` for the allocate-once-then-reuse idiom: ``out`` tensors that are ``[..., :N]`` views with a common pitch are
-        recognised and the call goes through rmav_rollout_pitched again."""
+        recognised and the call goes through rmav_rollout_pitched again.
+
+        ``layout="chunked"`` (device tensors, fused): the trajectory layout this GPU stores fastest for EVERY kind and batch size -
+        chunk-major ``[C, T, dim, chunk]`` / ``[C, T, chunk]`` with ``chunk = rmav_chunk_envs()`` (:meth:`rollout_chunked`): 65 536-env
+        chunks for quadrotor3d beyond 65 536 envs (131 072 envs: 0.67 -> 0.78 of the HBM roofline), ONE chunk (C = 1, i.e. the plain
+        feature-major array with a leading axis of 1) everywhere else.  A learner that flattens (step, env) samples - PPO2 does -
+        consumes it as it is: ``x.permute(0, 1, 3, 2).reshape(-1, dim)``; :meth:`unchunk` gives the plain ``[T, dim, N]`` copy."""
+        if layout == "chunked":
+            if not fused:
+                raise ValueError("layout='chunked' is a fused-rollout layout")
+            return self.rollout_chunked(n_steps, mode=mode, actions=actions, want=want, out=out)
         T = int(n_steps)
         m = _MODES[mode]
         a_in, mem = None, (A.DEVICE if device_out else A.HOST)

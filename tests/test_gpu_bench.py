@@ -56,12 +56,15 @@ def test_bench_driver_command_line_is_compact(built, tmp_path):
     # timed region = steps x ms_per_step fits in the process's run time by a wide margin
     assert j["steps"] * j["ms_per_step"] * 1e-3 < el
     legs = j["legs"]
-    for k in ("step", "step_262144", "step_1048576", "sustained"):
+    for k in ("step", "step_262144", "step_1048576", "sustained", "c3_shard", "c3_shard_chunked", "c4"):   # configs[2]'s shard and configs[3] ride along
         assert 0.0 < legs[k]["frac"] <= 1.0, (k, legs[k])
+    assert j["value_sustained"] == pytest.approx(legs["sustained"]["value"], rel=1e-3)
+    assert len(json.dumps(j, separators=(",", ":"))) < 4000 and el < 60.0      # (~30 s: 10 s + 3 s of CPU baselines, 11 s sustained)
     mt = j["cpu_mt"]
     assert mt["cores"] <= mt["cores_available"] and mt["value"] > 0
     full = json.load(open(d))
     assert full["other_modes"]["step_1048576"]["roofline"]["bytes_per_launch"] == 1048576 * 101
+    assert full["other_modes"]["sustained"]["seconds"] >= 10.0              # long enough for a 5 s busy sampler to see twice
     assert full["host_cpus"]["usable"] >= 1 and "cgroup_source" in full["host_cpus"]
     assert len(r.stderr) < 2000, r.stderr[-2000:]     # stderr stays quiet: the driver's tail appends it to stdout's
 

@@ -51,6 +51,7 @@ bench)
   ;;
 legs)
   timeout 600 $B --envs-per-gpu 131072 --cpu-seconds 0 --no-secondary > $OUT/bench_c3shard.json 2>/dev/null; line $OUT/bench_c3shard.json
+  timeout 600 $B --envs-per-gpu 131072 --layout soa --cpu-seconds 0 --no-secondary > $OUT/bench_c3shard_plain.json 2>/dev/null; line $OUT/bench_c3shard_plain.json
   timeout 600 $B --kind quad3d_sl --envs-per-gpu 262144 --steps 500 --warmup 100 --cpu-seconds 0 --no-secondary > $OUT/bench_c4.json 2>/dev/null; line $OUT/bench_c4.json
   ;;
 sweep)
@@ -81,7 +82,7 @@ sq)
   EXTRA="$EXTRA" bash tools/pmc_sq.sh $TAG/sq > $OUT/sq_counters.txt 2>&1; tail -40 $OUT/sq_counters.txt
   ;;
 prof)
-  bash tools/profile_round.sh $TAG ${ROUND:-r03} 2>&1 | tail -60
+  bash tools/profile_round.sh $TAG ${ROUND:-r06} 2>&1 | tail -60
   ;;
 actors)
   bash tools/profile_actors.sh $TAG 2>&1 | tail -14

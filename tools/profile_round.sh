@@ -3,7 +3,7 @@
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950: TCC has 4 slots, they need 3 + 2; no --stats with --pmc).
 # Usage (via gpurun, from the repo root): bash tools/profile_round.sh <tag> [round]     e.g.  r03_p r03
 # Writes gpurun_out/<tag>/prof/{summary.md, traffic.json, trace_*, pmc_*}; tools/collect_profiles.sh copies the judged files.
-TAG=${1:-r05_p}; ROUND=${2:-r05}
+TAG=${1:-r06_p}; ROUND=${2:-r06}
 OUT=$PWD/gpurun_out/$TAG/prof
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -24,7 +24,8 @@ CASES=(
   "c2_step_lazy|--mode step --steps 3000 --warmup 300 --tune step_lazy=1"
   "step_262144|--mode step --envs-per-gpu 262144 --steps 2000 --warmup 300"
   "step_1048576|--mode step --envs-per-gpu 1048576 --steps 800 --warmup 200"
-  "c3shard_ring|--envs-per-gpu 131072 --steps 1000 --warmup 100"
+  "c3shard_ring|--envs-per-gpu 131072 --layout soa --steps 1000 --warmup 100"
+  "c3shard_chunked|--envs-per-gpu 131072 --layout chunked --steps 1000 --warmup 100"
   "c4_ring|--kind quad3d_sl --envs-per-gpu 262144 --steps 400 --warmup 50"
 )
 # the secondary legs whose kernels have no bench case of their own: C4 with per-env constants (k_rollout<3, 5, 1> of THIS run is that leg only),
