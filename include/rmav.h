@@ -111,25 +111,10 @@ enum rmav_action_mode {
     RMAV_ACT_BUFFER = 0,    /* actions read from a caller buffer */
     RMAV_ACT_RANDOM = 1,    /* uniform in [act_lo, act_hi) from the counter RNG, generated in-kernel */
     RMAV_ACT_CONTROLLER = 2, /* the reference's geometric controller, evaluated in-kernel */
-    RMAV_ACT_POLICY = 3,     /* Gaussian MLP policy evaluated in-kernel, fp32 (rmav_rollout_policy only) */
-    RMAV_ACT_POLICY_BF16 = 4 /* the same policy on the matrix cores: bf16 operands, fp32 accumulate */
+    RMAV_ACT_POLICY = 3,     /* Gaussian MLP policy evaluated in-kernel (rmav_rollout_policy only: rmav_ppo.h) */
+    RMAV_ACT_POLICY_BF16 = 4 /* the same policy on the matrix cores */
 };
 enum rmav_integrator { RMAV_INT_EULER = 0, RMAV_INT_RK4 = 1 };
-enum rmav_policy_precision {
-    RMAV_POLICY_FP32 = 0,       /* fp32 FMAs on the vector ALU */
-    RMAV_POLICY_BF16_MFMA = 1,  /* bf16 operands, fp32 accumulate on the matrix cores */
-    RMAV_POLICY_FP32_MFMA = 2,  /* fp32 operands and accumulate on the fp32-input matrix instructions: same precision
-                                   class as RMAV_POLICY_FP32 (only the summation order differs), ~2x its speed */
-    RMAV_POLICY_F16_MFMA = 3,   /* f16 operands (11-bit mantissa), fp32 accumulate, tanh folded into the next layer's weights
-                                   (csrc/rmav_policy_pair.hpp): ~8x closer to the fp32 policy than bf16 and faster.
-                                   Weight buffer: rmav_pack_policy_f16 */
-    RMAV_POLICY_F16_SHARED = 4  /* a DIFFERENT architecture, same arithmetic as RMAV_POLICY_F16_MFMA: ONE 2x64 tanh trunk with a mean head
-                                   and a scalar value head on its latent - baselines' value_network = 'shared', what ppo2 builds for an env
-                                   type without a defaults entry (the native envs of gym_reinmav: env_type 'native'); the other precisions
-                                   evaluate a policy net and a separate value net (value_network = 'copy', baselines' MuJoCo default).
-                                   Weight buffer: rmav_policy_weight_count_shared() floats = ONE net of the bf16 fragment layout with
-                                   output rows 0..3 = the mean head, row 4 = the value head, then logstd [4]; built by rmav_pack_policy_f16 */
-};
 
 /* rmav_create flags */
 #define RMAV_F_AUTO_RESET 1u     /* VecEnv semantics: a done env is reset inside step; the returned
@@ -201,27 +186,20 @@ int rmav_set_stream(rmav_handle h, void *hip_stream);
  * or NULL to go back to the shared value of rmav_params.  Quadrotor kinds only. */
 enum rmav_env_param { RMAV_PARAM_MASS = 0, RMAV_PARAM_LOAD_MASS = 1, RMAV_PARAM_TETHER_LENGTH = 2 };
 int rmav_set_env_param(rmav_handle h, int which, const float *values, int mem);
-/* Explicit, per-handle overrides of the launch heuristics (DESIGN.md section 4 states the automatic rules and the
- * measurements behind them).  -1 = automatic (the default for every key).  Results never depend on these: every
- * variant produces the same bits (tests/test_gpu_parity.py::test_rollout_bits_do_not_depend_on_kernel_variant). */
+/* Explicit, per-handle overrides of the launch rules (DESIGN.md section 4 states the automatic rules and what was measured).
+ * -1 = automatic, the default of every key.  Results never depend on them: every variant writes the same bits
+ * (tests/test_gpu_parity.py::test_kernel_selection_variants_give_the_same_bits, ::test_single_step_variants_give_the_same_bits). */
 enum rmav_tuning_key {
-    RMAV_TUNE_SPLIT = 0,           /* fused rollouts: 0 = one wavefront per 64 envs, 1 = integrator + memory wavefront pairs */
-    RMAV_TUNE_SLICE = 1,           /* batches beyond the two-wavefront capacity: 0 = one launch, 1 = one launch per slice */
-    RMAV_TUNE_STORE_POLICY = 2,    /* trajectory stores: 0 write-back, 1 write-through, 2 non-temporal, 3 LDS-transposed AoS */
-    RMAV_TUNE_SPLIT_GROUP = 3,     /* (integrator, memory wavefront) pairs per workgroup, 1 .. 8 */
-    RMAV_TUNE_BLOCK = 4,           /* workgroup size of the one-wavefront kernels: 64 | 128 | 256 */
-    RMAV_TUNE_STEP_KERNEL = 5,     /* 0: single-step calls use the rollout kernel at n_steps = 1 instead of k_step */
-    RMAV_TUNE_SPLIT_MIN_STEPS = 6, /* shortest fused launch that may use the two-wavefront kernel (default 2) */
-    RMAV_TUNE_LEAN = 7,            /* 0: the two-wavefront kernel's memory wavefront uses the generic (pointer-advancing) drain */
-    RMAV_TUNE_STEP_LAZY = 8,       /* 1: k_step loads steps_beyond_done / reset counters only in lanes whose env terminates */
-    RMAV_TUNE_SLICE_ENVS = 9,      /* E >= 64: fused rollouts as two-wavefront launches over slices of at most E envs */
-    RMAV_TUNE_HOST_FLAG = 10,      /* 0: host-pointer single-wavefront steps wait with hipStreamSynchronize instead of the pinned completion word */
-    RMAV_TUNE_POLICY_PAIR = 11,    /* RMAV_POLICY_BF16_MFMA: 0 = one wavefront per 64 envs (round 3's kernel) instead of the (actor, critic) pair */
-    RMAV_TUNE_PAIR_GROUP = 12,     /* (actor, critic) wavefront pairs per workgroup of the matrix-core actors, 1 .. 4 */
-    RMAV_TUNE_STEP_STORE = 13,     /* cache policy of k_step's per-env stores: 0 write-back (default), 1 write-through, 2 non-temporal */
-    RMAV_TUNE_ROLE_SWAP = 14,      /* two-wavefront kernels: 1 + s = alternate which half of a workgroup integrates by bit s of the workgroup index */
-    RMAV_TUNE_FIXED_FLAGS = 15,    /* two-wavefront kernels: 0 = never take the variant with the usual launch options compiled in (bits are the same) */
-    RMAV_TUNE_COUNT = 16
+    RMAV_TUNE_SPLIT = 0,        /* fused rollouts: 0 = one wavefront per 64 envs, 1 = (integrator, memory) wavefront pairs */
+    RMAV_TUNE_SLICE = 1,        /* batches beyond the pair kernel's capacity: 0 = one launch, 1 = one launch per balanced slice */
+    RMAV_TUNE_STORE_POLICY = 2, /* trajectory stores: 0 write-back, 1 write-through, 2 non-temporal, 3 LDS-transposed batch-major obs */
+    RMAV_TUNE_SPLIT_GROUP = 3,  /* (integrator, memory) pairs per workgroup, 1 .. 8 */
+    RMAV_TUNE_BLOCK = 4,        /* workgroup size of the one-wavefront kernels: 64 | 128 | 256 */
+    RMAV_TUNE_STEP_LAZY = 5,    /* rmav_step: 1 = the env's termination record is loaded only in lanes whose episode ends */
+    RMAV_TUNE_STEP_STORE = 6,   /* rmav_step's per-env stores: 0 write-back, 1 write-through, 2 non-temporal */
+    RMAV_TUNE_POLICY_PAIR = 7,  /* RMAV_POLICY_BF16_MFMA: 0 = one wavefront per 64 envs instead of the (actor, critic) pair */
+    RMAV_TUNE_PAIR_GROUP = 8,   /* (actor, critic) pairs per workgroup of the matrix-core actors, 1 .. 4 */
+    RMAV_TUNE_COUNT = 9
 };
 int rmav_set_tuning(rmav_handle h, int key, int value);
 int rmav_get_tuning(rmav_handle h, int key, int *value_out);
@@ -264,164 +242,26 @@ int rmav_rollout(rmav_handle h, int32_t n_steps, int action_mode, const float *a
 
 /* rmav_rollout with a column pitch: device pointers, feature-major arrays whose feature columns are `pitch` elements apart -
  * actions_in / actions_out [n_steps][nA][pitch], obs_out [n_steps][nS][pitch], rew_out / done_out [n_steps][pitch]; env i is
- * element i of every column, elements [N, pitch) are never written.  Same results as rmav_rollout.  Why: with the plain layout
- * a batch size that is not a multiple of 16 starts every column off a 64-byte line, every wavefront's 256-byte store ends in
- * partial lines, and the library has to fall back to write-back stores (65 599 envs: 67.7 us per 64-step launch against 48.8
- * for 65 600 on one box; 1 048 575: 1 564 against 730).  rmav_trajectory_pitch() = N rounded up to a multiple of 64 (so that
- * the byte-wide done rows start on a line as well) takes the batch size out of it; any pitch >= N is accepted. */
+ * element i of every column, elements [N, pitch) are never written.  Same results as rmav_rollout.  Keeps the fast store path
+ * for batch sizes that are not a multiple of 16.  rmav_trajectory_pitch() = N rounded up to a multiple
+ * of 64; any pitch >= N is accepted. */
 int64_t rmav_trajectory_pitch(rmav_handle h);
 int rmav_rollout_pitched(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
                          float *obs_out, float *rew_out, uint8_t *done_out, int64_t pitch, int fused);
 
-/* rmav_rollout (fused) with CHUNK-MAJOR trajectory arrays: the env range is cut into chunks of chunk_envs (a multiple of 64; the last
- * one may be shorter) and chunk c's trajectory is a dense array of its own,
- *   actions_in / actions_out [n_chunks][n_steps][nA][chunk_envs], obs_out [n_chunks][n_steps][nS][chunk_envs], rew_out / done_out
- *   [n_chunks][n_steps][chunk_envs]    (env i = chunk i / chunk_envs, column i % chunk_envs; device pointers; same values as rmav_rollout).
- * Why: the fused rollout of quadrotor3d is bound by its trajectory stores, and a launch over 65 536 envs writing ONE dense region is what
- * the store stream of this GPU likes best; slicing a big batch into such launches does not help as long as every launch writes a strided
- * half / quarter of arrays laid out for the whole batch (a 65 536-env launch into arrays of pitch 131 072: 53 us instead of 40 - 42), with
- * chunk-major arrays it does.  Measured (profiles/r05/chunk_probe.md, one box, 64-step launches): quadrotor3d random actions 131 072 envs
- * 91.2 -> 87.1 us (0.72 -> 0.75 of the 8 TB/s roofline), 262 144 envs 190.2 -> 175.2 (0.69 -> 0.75), 1 048 576 unchanged; the slung-load
- * kinds, controller-driven rollouts and the 2-D kinds are 3 - 10 % SLOWER chunked (their launches are not store-bound), so
- * rmav_chunk_envs() recommends a chunk only for quadrotor3d beyond 65 536 envs and returns N rounded up to a multiple of 64 (one chunk = the
- * plain layout, with that column pitch when N % 64 != 0) otherwise.
- * A learner that flattens (step, env) samples anyway - PPO2 does - consumes the chunks as they are.
- * n_steps >= 2; chunk_envs a multiple of 64, at most the two-wavefront kernel's capacity (131 072; 65 536 for controller-driven slung-load). */
+/* rmav_rollout (fused) with CHUNK-MAJOR trajectory arrays: the env range is cut into chunks of chunk_envs (a multiple of 64; the
+ * last one may be shorter) and chunk c's trajectory is a dense array of its own,
+ *   actions_in / actions_out [n_chunks][n_steps][nA][chunk_envs], obs_out [n_chunks][n_steps][nS][chunk_envs],
+ *   rew_out / done_out [n_chunks][n_steps][chunk_envs]   (env i = chunk i / chunk_envs, column i % chunk_envs; device pointers).
+ * Same values as rmav_rollout; one launch per chunk, each writing one dense region - the layout this GPU stores fastest for
+ * big quadrotor3d batches (131 072 envs: 0.65 -> 0.78 of the HBM roofline).  rmav_chunk_envs() is the
+ * recommended chunk: 65 536 for quadrotor3d beyond 65 536 envs, otherwise N rounded up to a multiple of 64 (one chunk = the
+ * plain layout, with that column pitch when N % 64 != 0).  A learner that flattens (step, env) samples - PPO2 does - consumes
+ * the chunks as they are.  chunk_envs < N needs n_steps >= 2 and chunk_envs <= the pair kernel's capacity (131 072; 65 536
+ * for controller-driven slung-load); RMAV_ACT_BUFFER does not echo the caller's actions (actions_out must be NULL). */
 int64_t rmav_chunk_envs(rmav_handle h);
 int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const float *actions_in, float *actions_out,
                          float *obs_out, float *rew_out, uint8_t *done_out, int64_t chunk_envs);
-
-/* PPO2-style rollout with the policy inside the kernel (the caller loop of gym_reinmav/run.py:63-68:
- * baselines ppo2 Runner = model.step(obs) -> env.step(actions), network='mlp').  Policy: two 64-unit tanh
- * layers -> Gaussian mean (state-independent log-std), plus a value net of the same shape.  All pointers
- * are DEVICE pointers, layout is SoA, nothing synchronises (capturable in a hipGraph).
- * weights: rmav_policy_weight_count(kind) floats, 16-byte aligned, layout (H = 64, NSP = nS rounded up
- *   to a multiple of 4), policy net then value net, each:
- *     W1 [H][NSP] (row = hidden unit, zero padded) | b1 [H] | W2T [H][H] (W2T[i][j] = W2[j][i]) | b2 [H] |
- *     W3T [H][4] (W3T[j][k] = W3[k][j], zero padded to 4 outputs) | b3 [4]
- *   then logstd [4] (zero padded).
- * Per step t: a = mean(obs_t) + exp(logstd) * z_t with z_t standard normal from the counter RNG
- * (stream tag 3, Box-Muller; see csrc/rmav_policy.hpp), logp_out[t] = log N(a; mean, std),
- * value_out[t] = V(obs_t); value_out[n_steps] = V(obs after the last step) for bootstrapping.
- * actions_out [n_steps][nA][N], obs_out [n_steps][nS][N], rew_out / done_out [n_steps][N] may be NULL.
- * precision = RMAV_POLICY_BF16_MFMA evaluates the same two nets with v_mfma_f32_32x32x16_bf16 (bf16
- * weights and activations, fp32 accumulation; means / values within ~1e-2 of the fp32 policy).  Its weight
- * buffer is rmav_policy_weight_count_bf16() floats of pre-arranged MFMA fragments: per net
- *   A1 [2][64 lanes][8 bf16] | A2 [2][4][64][8] | A3 [4][64][8] | b1 [64] | b2 [64] | b3 [32] (fp32)
- * then logstd [4]; fragment (.., lane = (m = lane & 31, h = lane >> 5), j) holds
- *   layer 1: W1p[32 Mt + m][8 h + j]              (W1 zero-padded to 16 inputs)
- *   layer 2: W2 [32 Mt + m][rowmap(s, h, j)]
- *   layer 3: W3p[m][rowmap(s, h, j)]               (W3 zero-padded to 32 outputs)
- *   rowmap(s, h, j) = 32 (s >> 1) + (r & 3) + 8 (r >> 2) + 4 h,  r = 8 (s & 1) + j
- * (csrc/rmav_policy_mfma.hpp explains why; gym_reinmav_amd.ppo.pack_policy_weights_bf16 builds it). */
-int64_t rmav_policy_weight_count(int kind);
-int64_t rmav_policy_weight_count_bf16(void);
-/* RMAV_POLICY_FP32_MFMA: rmav_policy_weight_count_f32_mfma() floats of pre-arranged A operands of
- * v_mfma_f32_32x32x2_f32, per net (policy, then value):
- *   A1 [2 T][2 sq][64 lanes][4]          lane (m, h), entry j: W1p[32 T + m][2 (4 sq + j) + h]   (W1 zero-padded to 16 inputs)
- *   A2 [2 To][2 Tin][4 rq][64 lanes][4]  lane (m, h), entry j: W2[32 To + m][32 Tin + row(4 rq + j, h)]
- *   W3 [2 h][4 outputs][32]              entry 16 Tin + r:      W3p[o][32 Tin + row(r, h)]        (W3 zero-padded to 4 outputs)
- *   b1 [64] | b2 [64] | b3 [4]
- * then logstd [4];  row(r, h) = (r & 3) + 8 (r >> 2) + 4 h  (csrc/rmav_policy_mfma32.hpp explains why;
- * gym_reinmav_amd.ppo.pack_policy_weights_f32_mfma builds it). */
-int64_t rmav_policy_weight_count_f32_mfma(void);
-int64_t rmav_policy_weight_count_shared(void);   /* RMAV_POLICY_F16_SHARED */
-/* Builds such a weight buffer on the device in ONE launch on the handle's stream: with `flat` = the concatenation of the
- * n_params (<= 16) parameter tensors `params[k]` (DEVICE pointers in a HOST array; sizes[k] elements each) followed by zeros,
- * weights_out[i] = flat[idx_lo[i]] when idx_hi[i] < 0, else the two bf16 roundings of flat[idx_lo[i]] (low half) and
- * flat[idx_hi[i]] (high half) in one 32-bit word.  idx_lo / idx_hi: int32 [n_out] on the DEVICE - the fixed permutation of a
- * layout above (gym_reinmav_amd.ppo._PolicyPacker builds them once).  Replaces the chain of small tensor operations a
- * learner would otherwise run before every rollout (baselines: model.step reads the live variables; here the actor's copy
- * is re-derived from the learner's parameters). */
-int rmav_pack_policy(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
-                     const int32_t *idx_hi, int64_t n_out, float *weights_out);
-/* RMAV_POLICY_F16_MFMA: the bf16 layout above with f16 pairs in the fragment words (same idx_lo / idx_hi maps, n_out =
- * rmav_policy_weight_count_bf16()), and the fragments of layers 2 and 3 pre-multiplied (in fp32, before the one rounding to
- * f16) by -2 k and -2, k = 2 log2(e): the kernel hands r = 1 / (1 + e^(2z)) = (1 - tanh z) / 2 to the next layer instead of
- * tanh z and derives the matching biases b' = b + rowsum(W) from these rounded weights when it stages them
- * (gym_reinmav_amd.ppo.pack_policy_weights_f16 is the torch form of the same buffer). */
-int rmav_pack_policy_f16(rmav_handle h, int n_params, const float *const *params, const int64_t *sizes, const int32_t *idx_lo,
-                         const int32_t *idx_hi, int64_t n_out, float *weights_out);
-int rmav_rollout_policy(rmav_handle h, int32_t n_steps, const float *weights, float *actions_out,
-                        float *obs_out, float *rew_out, uint8_t *done_out, float *logp_out,
-                        float *value_out, int precision);
-
-/* ---- learner-side passes over a trajectory (DEVICE pointers, enqueued on the handle's stream) -------- */
-/* Generalised advantage estimation, the backward pass of baselines ppo2 Runner.run():
- *   delta_t = reward_scale * r_t + gamma V_{t+1} (1 - done_t) - V_t,  A_t = delta_t + gamma lam (1 - done_t) A_{t+1}
- * rew [n_steps][N], done u8 [n_steps][N] (1 = the episode ended with step t), values [n_steps + 1][N]
- * (values[n_steps] = bootstrap value; exactly what rmav_rollout_policy writes); adv_out, ret_out [n_steps][N]
- * (ret = A + V).  sums_out (nullable): 2 doubles on the device <- (sum A, sum A^2) over all n_steps*N samples,
- * for the advantage normalisation (all-reduce them across ranks first when data parallel).  fp32 FMAs;
- * agrees with a float64 per-env recursion to ~1e-6 relative. */
-int rmav_gae(rmav_handle h, int32_t n_steps, const float *rew, const uint8_t *done, const float *values,
-             float gamma, float lam, float reward_scale, float *adv_out, float *ret_out, double *sums_out);
-/* x[i] <- (x[i] - mean) * rstd for i < count (x 16-byte aligned): advantage normalisation in place. */
-int rmav_normalize(rmav_handle h, float *x, int64_t count, float mean, float rstd);
-
-/* ---- multi-GPU: the path's one collective ------------------------------------------ */
-/* Envs shard over ranks by contiguous ranges of GLOBAL env id: rank r of W owns base + (r < rem) envs
- * starting at r*base + min(r, rem), base = n_total / W, rem = n_total % W (create each rank's handle with
- * env_id_base = that start).  The data path needs no communication; the only exchange is the all-gather of
- * per-env episode statistics once per rollout.  The communicator wraps an RCCL communicator (librccl.so.1 is
- * loaded on first use; one process per GPU).  Rank 0 calls rmav_comm_unique_id and hands the 128 bytes to the
- * other ranks out of band (file, MPI, a torch store ...); every rank then calls rmav_comm_create. */
-typedef struct rmav_comm_s *rmav_comm;
-#define RMAV_COMM_ID_BYTES 128
-/* Optional, before any other rmav_comm_* call of the process: resolve the five collective entry points (ncclGetUniqueId,
- * ncclCommInitRank, ncclCommDestroy, ncclAllGather, ncclGetErrorString) from THIS shared object instead of librccl.so.1 - a
- * site's own RCCL build, or the test suite's stand-in that lets two rank processes share ONE GPU (tests/stub_rccl). */
-int rmav_comm_use_library(const char *path);
-int rmav_comm_unique_id(void *id_out /* RMAV_COMM_ID_BYTES bytes, host */);
-int rmav_comm_create(rmav_comm *out, const void *id, int rank, int world, int device);
-int rmav_comm_destroy(rmav_comm c);
-/* What the communicator is: rank / world as passed to rmav_comm_create, and what the collective library itself reports for its
- * communicator (ncclCommUserRank / ncclCommCount; -1 when the library does not export them).  Any pointer may be NULL.  Lets a
- * launcher assert that RCCL really connected `world` ranks (the role of the MPI rank probe of gym_reinmav/run.py:18-21,177-182). */
-int rmav_comm_info(rmav_comm c, int *rank_out, int *world_out, int *lib_rank_out, int *lib_world_out);
-/* One tiny all-gather on the communicator's own stream, awaited on the HOST for at most timeout_s seconds (< 0: no limit):
- * RMAV_OK, or RMAV_ERR_TIMEOUT.  RCCL connects its transports inside the FIRST collective's enqueue - a host-side exchange
- * with the peers that blocks when one of them is gone - so a caller that wants a bounded set-up runs rmav_comm_create +
- * rmav_comm_warmup on a helper thread and joins it with a deadline (gym_reinmav_amd.distributed.NativeStatsExchange does);
- * no handle and no handle's stream is involved. */
-int rmav_comm_warmup(rmav_comm c, double timeout_s);
-/* returns_out f32 [n_total], lengths_out i32 [n_total] (DEVICE pointers) <- return / length of every env's most
- * recently finished episode, in global env order, on every rank.  Enqueued on the handle's stream (pack ->
- * ncclAllGather over xGMI -> unpack); does not synchronise.  Needs RMAV_F_TRACK_EPISODES. */
-int rmav_allgather_stats(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
-/* The same exchange in two halves, so that it overlaps the next rollout: _post packs this rank's payload on the
- * handle's stream (a stream-ordered snapshot) and runs the ncclAllGather on the communicator's OWN (high-priority)
- * stream behind a signal word; up to eight exchanges may be in flight, and a ninth post blocks the HOST until the
- * oldest one has finished (back pressure - nothing is ever inserted into the handle's stream).  _result makes the
- * handle's stream wait for the most recently posted gather and unpacks it.  rmav_allgather_stats = _post followed
- * by _result.  ~15 us of host time per post (two small launches, one event record, one RCCL enqueue). */
-int rmav_allgather_stats_post(rmav_handle h, rmav_comm c, int64_t n_total);
-/* Optional, BEFORE the rollout whose statistics the next _post will exchange: the next fused rmav_rollout /
- * rmav_rollout_policy launch of `h` then writes the snapshot itself (every wavefront stores its envs' statistics into
- * the exchange's send buffer and publishes an arrival word; the communicator's stream polls those), so that _post puts
- * NOTHING into the handle's stream - no pack kernel, no signal kernel (~8 us per post at 131 072 envs).  Same snapshot,
- * same result.  Only a call that is ONE fused launch over all of the handle's envs takes the snapshot; if none happens
- * between _arm and _post (single-step launches incl. rmav_rollout(fused = 0), a sliced launch), or if another stepping
- * launch follows the one that took it, _post packs as usual.  The communicator stream's wait for the armed launch is
- * bounded: 2 s counted from the moment that launch BEGINS on the device (it may sit behind any amount of queued work first;
- * controller-driven rollouts of <= 131 072 envs publish no start word and are bounded by the waiter's overall 10 min only).
- * Past that the waiter poisons this rank's payload - return NaN, length -1 for each of its envs, on every rank - and the
- * collective is issued all the same, so no peer hangs; rmav_allgather_stats_wait (and _result, once the waiter has run)
- * return RMAV_ERR_TIMEOUT for THAT post only: later posts on the communicator are unaffected.  One armed exchange per handle
- * and per communicator at a time; _post with the same communicator consumes it; destroying the communicator or the handle
- * disarms the other. */
-int rmav_allgather_stats_arm(rmav_handle h, rmav_comm c, int64_t n_total);
-int rmav_allgather_stats_result(rmav_handle h, rmav_comm c, int64_t n_total, float *returns_out, int32_t *lengths_out);
-/* HOST-side bounded wait for the most recently posted exchange (polls its completion event; touches no stream):
- * RMAV_OK once the gather has finished, RMAV_ERR_TIMEOUT after timeout_s seconds (< 0: no limit).  Lets a caller probe a
- * freshly created communicator - post, wait with a deadline, only then _result - without ever parking a handle's stream
- * behind a collective that may never complete. */
-int rmav_allgather_stats_wait(rmav_comm c, double timeout_s);
-/* The send side of that exchange alone, for callers that own the collective (torch.distributed over RCCL):
- * send_out i32 [2][cmax] (DEVICE) <- bit patterns of the per-env last returns, then the last lengths, zero padded
- * from num_envs to cmax (the largest shard).  A stream-ordered snapshot in one small launch, so the next
- * rollout may overwrite the per-env arrays while the collective is still in flight. */
-int rmav_pack_stats(rmav_handle h, int64_t cmax, int32_t *send_out);
 
 /* ---- state access (also the env checkpoint) ------------------------------------------------ */
 int rmav_get_state(rmav_handle h, float *out, int mem, int layout);      /* nS*N floats */
@@ -445,4 +285,11 @@ int rmav_episode_buffers(rmav_handle h, float *last_return, int32_t *last_length
 #ifdef __cplusplus
 }
 #endif
+
+/* The two extensions of the path, each in its own header (included here, so that `#include "rmav.h"` declares everything):
+ *   rmav_ppo.h   SURVEY 8(f1): the PPO2 rollout loop with the policy inside the kernel, GAE, advantage normalisation
+ *   rmav_comm.h  SURVEY 8(e): the path's one collective - the all-gather of per-env episode statistics over RCCL / xGMI */
+#include "rmav_ppo.h"
+#include "rmav_comm.h"
+
 #endif /* RMAV_H */

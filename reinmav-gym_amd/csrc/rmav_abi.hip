@@ -193,14 +193,11 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         if (g > g_max) g = g_max;
         const int64_t per_wg = 64 * g;
         // lean addressing in the memory wavefront: feature-major, every trajectory array below 4 GiB (32-bit scalar step offsets)
-        if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * a.pitch < ((int64_t)1 << 30) && h->tune[RMAV_TUNE_LEAN] != 0)
-            a.flags |= F_LEAN;
-        // RMAV_TUNE_ROLE_SWAP = 1 + s: alternate the integrator / memory roles of the workgroup's halves by bit s of the workgroup index
-        if (const int rs = h->tune[RMAV_TUNE_ROLE_SWAP]; rs >= 1 && rs <= 4) a.flags |= F_ROLE_SWAP | ((uint32_t)(rs - 1) << 8);
+        if (!(a.flags & F_AOS) && (int64_t)a.n_steps * Dims<K>::NS * a.pitch < ((int64_t)1 << 30)) a.flags |= F_LEAN;
         const dim3 grid((unsigned)((count + per_wg - 1) / per_wg)), block(128 * g);
         bool launched = false;
         if constexpr (ST == ST_WRITE_THROUGH) {   // the usual options, compiled in (k_rollout's FIXED)
-            if ((a.flags & (F_AOS | F_TRACK | F_AUTO_RESET)) == (F_TRACK | F_AUTO_RESET) && h->tune[RMAV_TUNE_FIXED_FLAGS] != 0) {
+            if ((a.flags & (F_AOS | F_TRACK | F_AUTO_RESET)) == (F_TRACK | F_AUTO_RESET)) {
                 hipLaunchKernelGGL((k_rollout<K, MODE, ST, true>), grid, block, lds_per_pair * g, h->stream, a, p, pc);
                 launched = true;
             }
@@ -223,15 +220,9 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, boo
         return true;
     }
     // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
-    const int min_steps = h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] > 0 ? h->tune[RMAV_TUNE_SPLIT_MIN_STEPS] : 2;
-    if (a.n_steps < min_steps || h->kind > RMAV_QUAD3D_SL) return false;
+    if (a.n_steps < 2 || h->kind > RMAV_QUAD3D_SL) return false;
     const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
     if (forced == 0) return false;
-    // RMAV_TUNE_SLICE_ENVS = E (a multiple of 64): the two-wavefront kernel in launches of at most E envs each (measurement knob)
-    if (const int64_t e = h->tune[RMAV_TUNE_SLICE_ENVS]; e >= 64 && e < h->n && h->n <= 8 * e) {
-        *slices = (int)((h->n + e - 1) / e);
-        return true;
-    }
     if (h->n <= cap) return true;
     // Two rounds of the two-wavefront kernel - two launches over balanced halves of the env range - beat one launch of the
     // one-wavefront kernel for the slung-load kinds (fp64 integrator: the one-wavefront kernel holds only 3-4 of them per SIMD)
@@ -327,7 +318,7 @@ inline int step_store(rmav_handle h) {
     return v >= 0 ? v : ((h->n >= 196608 && h->n < 786432) ? (int)ST_STREAM : (int)ST_DEFAULT);
 }
 
-// n_steps == 1 with caller actions: the latency-cut single-step kernel (RMAV_TUNE_STEP_KERNEL = 0 falls back to k_rollout)
+// n_steps == 1 with caller actions: the latency-cut single-step kernel
 template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctrl) {
     if (h->xchg.armed && h->xchg.fired) h->xchg.stale = true;   // the armed launch's snapshot is no longer the latest
     const typename Env<K>::P p = derive_env<K>(h->params);
@@ -349,8 +340,7 @@ template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctr
 }
 
 int launch_rollout(rmav_handle h, int mode, const RolloutArgs &a) {
-    const bool step_kernel = h->tune[RMAV_TUNE_STEP_KERNEL] != 0;
-    if (step_kernel && a.n_steps == 1 && (mode == RMAV_ACT_BUFFER || mode == ACT_BUFFER_CTRL) && h->kind != RMAV_REINMAV) {
+    if (a.n_steps == 1 && (mode == RMAV_ACT_BUFFER || mode == ACT_BUFFER_CTRL) && h->kind != RMAV_REINMAV) {
         const bool ctrl = mode == ACT_BUFFER_CTRL;
         switch (h->kind) {
         case RMAV_QUAD2D: return launch_step_k<QUAD2D>(h, a, ctrl);
@@ -893,8 +883,7 @@ static int rollout_impl(rmav_handle h, int32_t n_steps, int action_mode, const f
     // One wavefront, one k_step launch, outputs in the pinned block: the kernel publishes its completion in a pinned word and
     // the host spins on that (bounded) instead of hipStreamSynchronize.  What the gym-shaped single env runs.
     bool flag_wait = false;
-    if (pinned && n_steps == 1 && h->n <= 64 && action_mode == RMAV_ACT_BUFFER && h->kind != RMAV_REINMAV &&
-        h->tune[RMAV_TUNE_STEP_KERNEL] != 0 && h->tune[RMAV_TUNE_HOST_FLAG] != 0) {
+    if (pinned && n_steps == 1 && h->n <= 64 && action_mode == RMAV_ACT_BUFFER && h->kind != RMAV_REINMAV) {
         if (!h->done_flag && hipHostMalloc((void **)&h->done_flag, 64, hipHostMallocMapped) == hipSuccess) {
             *h->done_flag = 0;
             if (hipHostGetDevicePointer((void **)&h->done_flag_dev, h->done_flag, 0) != hipSuccess) {

@@ -114,8 +114,7 @@ template <int K, int MODE> constexpr int split_words_per_pair() {
 }
 // F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
 // memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
-// F_ROLE_SWAP (+ bits 8..9: which bit of the workgroup index alternates the roles): see the role assignment at the top of k_rollout
-enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u, F_ROLE_SWAP = 16u };
+enum : uint32_t { F_AUTO_RESET = 1u, F_TRACK = 2u, F_AOS = 4u, F_LEAN = 8u };
 
 
 // What a lane needs only when its env's episode ends, as ONE 16-byte record per env (b128 / b96 accesses):
@@ -333,13 +332,10 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
     [[maybe_unused]] constexpr int CH = SplitTile<NS, NA, DRAWS>::CH;   // env-steps per hand-over (split modes)
     // SPLIT: G pairs per workgroup; threads [0, 64 G) are the integrators, [64 G, 128 G) their memory wavefronts
     const uint32_t split_g = SPLIT ? (blockDim.x >> 7) : 1u;
-    // Which wavefronts of the workgroup integrate and which move memory.  F_ROLE_SWAP alternates the roles by bit `role_shift` of
-    // the workgroup index (a measurement knob: if a workgroup's wavefronts go to consecutive SIMDs, one pair per workgroup puts two
-    // integrators on SIMDs 0 and 2 of a CU and two memory wavefronts on 1 and 3).  Measured: no difference for any kind with one
-    // pair per workgroup, slower with several (profiles/r04/two_d_kinds.md) - which wavefronts share a SIMD is not what bounds them.
+    // (Alternating the two roles between the halves by workgroup index was measured in round 4 - no difference with one pair per
+    // workgroup, slower with several, profiles/r04/two_d_kinds.md: which wavefronts share a SIMD is not what bounds them.)
     const bool upper_half = SPLIT && (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= split_g;
-    const bool role_swap = SPLIT && (a.flags & F_ROLE_SWAP) != 0 && ((blockIdx.x >> ((a.flags >> 8) & 3u)) & 1u) != 0;
-    const bool split_helper = upper_half != role_swap;
+    const bool split_helper = upper_half;
     const uint32_t split_local = threadIdx.x - (upper_half ? 64u * split_g : 0u);
     const uint32_t gi = a.slice_first + (SPLIT ? blockIdx.x * (64u * split_g) + split_local : blockIdx.x * blockDim.x + threadIdx.x);
     const uint32_t slice_end = a.slice_count ? a.slice_first + a.slice_count : (uint32_t)a.n;
@@ -1342,7 +1338,7 @@ __device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_
 //     gathered with v_readlane over the set bits of the `done` ballot (usually one bit) instead of shuffle
 //     reductions.  (k_rollout adds to the same slots with atomics; launches are stream-ordered, so they mix.)
 //
-// LAZY (rmav_set_tuning(RMAV_TUNE_STEP_LAZY, 1); measured, NOT the default): steps_beyond_done and the reset counter are
+// LAZY (the default from 786 432 envs; rmav_set_tuning(RMAV_TUNE_STEP_LAZY, 0 | 1) overrides): steps_beyond_done and the reset counter are
 // needed only by lanes whose env terminates (~1.3 % per step), so they are loaded under that predicate AFTER `done` is known -
 // 8 B per env-step less HBM-side traffic (the launch fetches 1.28 x its algorithmic bytes otherwise, of which these two
 // arrays are 0.08), but a dependent memory round trip on the critical path of every wavefront that has a finishing lane

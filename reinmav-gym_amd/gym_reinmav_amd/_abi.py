@@ -25,8 +25,7 @@ POLICY_FP32, POLICY_BF16_MFMA, POLICY_FP32_MFMA, POLICY_F16_MFMA, POLICY_F16_SHA
 INT_EULER, INT_RK4 = 0, 1
 F_AUTO_RESET, F_TRACK_EPISODES = 1, 2
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_TIMEOUT = 0, -1, -2, -3, -4, -5
-TUNE = {"split": 0, "slice": 1, "store_policy": 2, "split_group": 3, "block": 4, "step_kernel": 5, "split_min_steps": 6, "lean": 7, "step_lazy": 8, "slice_envs": 9, "host_flag": 10,
-        "policy_pair": 11, "pair_group": 12, "step_store": 13, "role_swap": 14, "fixed_flags": 15}
+TUNE = {"split": 0, "slice": 1, "store_policy": 2, "split_group": 3, "block": 4, "step_lazy": 5, "step_store": 6, "policy_pair": 7, "pair_group": 8}
 COMM_ID_BYTES = 128
 
 

@@ -88,8 +88,8 @@ class BatchedQuadrotor:
         A.check(self._lib.rmav_sync(self._h))
 
     def set_tuning(self, **kv):
-        """Explicit overrides of the launch heuristics (``rmav_set_tuning``): split, slice, store_policy, split_group,
-        block, step_kernel, split_min_steps; -1 = automatic.  Results never depend on them."""
+        """Explicit overrides of the launch rules (``rmav_set_tuning``, ``_abi.TUNE``): split, slice, store_policy, split_group,
+        block, step_lazy, step_store, policy_pair, pair_group; -1 = automatic.  Results never depend on them."""
         for k, v in kv.items():
             A.check(self._lib.rmav_set_tuning(self._h, A.TUNE[k], int(v)))
 

@@ -10,7 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    txt = open(os.path.join(ROOT, "include", "rmav.h")).read()
+    inc = os.path.join(ROOT, "include")   # rmav.h (the core) + rmav_ppo.h, rmav_comm.h (its two extensions)
+    txt = "".join(open(os.path.join(inc, f)).read() for f in sorted(os.listdir(inc)) if f.endswith(".h"))
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(rmav_[a-z0-9_]+)\s*\(", txt)))
 

@@ -105,25 +105,29 @@ def test_gym_env_cached_control_is_the_real_control(G, kind):
 @pytest.mark.parametrize("kind", KINDS)
 def test_host_steps_with_the_pinned_completion_word(G, kind, n):
     """Host-pointer steps of a batch that fits one wavefront end with the kernel publishing a sequence number in a pinned
-    word the host spins on (instead of hipStreamSynchronize).  Same results as with the stream synchronise (tuning key
-    host_flag = 0), over 200 steps with auto-reset and tracking, for rmav_step and rmav_step_control; device state agrees."""
+    word the host spins on (instead of hipStreamSynchronize).  Same results as the same steps through DEVICE pointers (no
+    completion word, the caller synchronises), over 200 steps with auto-reset and tracking, for rmav_step and
+    rmav_step_control; device state agrees."""
+    import torch
+
     lo, hi = (0.0, 10.0) if kind == "quad3d" else (-10.0, 10.0)
     acts = np.random.RandomState(1).uniform(lo, hi, (200, n, NA[kind])).astype(np.float32)
     out = []
-    for flag in (1, 0):
+    for host in (True, False):
         env = G.BatchedQuadrotor(kind, n, seed=4, auto_reset=True, track_episodes=True)
-        env.set_tuning(host_flag=flag)
         rec = []
         for k in range(200):
-            r = env.step(acts[k]) if k % 2 else env.step_control(acts[k])
-            rec.append([np.array(x, copy=True) for x in r])
-        rec.append([env.get_state(), env.get_sbd(), env.get_reset_counts()])
+            a = acts[k] if host else torch.from_numpy(acts[k]).cuda()
+            r = env.step(a) if k % 2 else env.step_control(a)
+            if not host:
+                torch.cuda.synchronize()
+            rec.append([np.array(x if host else x.cpu().numpy(), copy=True).astype(np.float32) for x in r])
+        rec.append([env.get_state(), env.get_sbd().astype(np.float32), env.get_reset_counts().astype(np.float32)])
         out.append(rec)
         env.close()
     for ra, rb in zip(*out):
         for x, y in zip(ra, rb):
             assert np.array_equal(x, y)
-    assert any(r[2].any() for r in out[0][:200])      # some env terminated and was reset on the way
 
 
 def test_vec_env_reuse_buffers(G):

@@ -313,11 +313,9 @@ def test_kernel_selection_variants_give_the_same_bits(G, kind, n):
     for name, tune in (("default", {}), ("one wavefront", {"split": 0, "slice": 0}),
                        ("two wavefronts, one launch", {"split": 1, "slice": 0}),
                        ("two wavefronts, sliced", {"slice": 1}),
-                       ("two wavefronts, generic drain, 3 pairs per workgroup", {"split": 1, "slice": 0, "lean": 0, "split_group": 3}),
+                       ("two wavefronts, 3 pairs per workgroup", {"split": 1, "slice": 0, "split_group": 3}),
                        ("one wavefront, 64-thread workgroups, write-back stores", {"split": 0, "block": 64, "store_policy": 0}),
-                       ("two wavefronts, one pair per workgroup, roles alternating", {"split": 1, "slice": 0, "split_group": 1, "role_swap": 1}),
-                       ("two wavefronts, roles alternating by pairs of workgroups", {"split": 1, "slice": 0, "role_swap": 2}),
-                       ("two wavefronts, launch options read at run time", {"split": 1, "slice": 0, "fixed_flags": 0})):
+                       ("two wavefronts, one pair per workgroup, non-temporal stores", {"split": 1, "slice": 0, "split_group": 1, "store_policy": 2})):
         env = G.BatchedQuadrotor(kind, n, seed=5, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
         h = hashlib.sha256()
@@ -423,9 +421,8 @@ def test_episode_lengths_across_launch_kinds_and_counter_moves(G, kind):
 
 @pytest.mark.parametrize("kind", KINDS)
 def test_single_step_variants_give_the_same_bits(G, kind):
-    """rmav_step through k_step (batch- and feature-major), its write-through / non-temporal store variants, k_step with
-    lane-predicated counter loads
-    (RMAV_TUNE_STEP_LAZY) and the rollout kernel at n_steps = 1 (RMAV_TUNE_STEP_KERNEL = 0): same outputs, state, counters and
+    """rmav_step through k_step (batch- and feature-major), its write-through / non-temporal store variants and k_step with
+    the termination record loaded only in finishing lanes (RMAV_TUNE_STEP_LAZY): same outputs, state, counters and
     episode statistics, bit for bit, over 60 steps with ~1 % of the lanes terminating per step (ragged batch: the last
     wavefront has clones)."""
     import hashlib
@@ -436,7 +433,7 @@ def test_single_step_variants_give_the_same_bits(G, kind):
     digests = {}
     for name, tune, layout in (("k_step", {}, "aos"), ("feature-major", {}, "soa"), ("write-through", {"step_store": 1}, "aos"),
                                ("non-temporal", {"step_store": 2}, "soa"), ("lazy", {"step_lazy": 1}, "aos"),
-                               ("rollout kernel", {"step_kernel": 0}, "aos")):
+                               ("lazy, 128-thread workgroups", {"step_lazy": 1, "block": 128}, "soa")):
         env = G.BatchedQuadrotor(kind, n, seed=8, auto_reset=True, track_episodes=True)
         env.set_tuning(**tune)
         h = hashlib.sha256()

@@ -6,7 +6,7 @@
 #   bench     bench.py with its defaults, and with the driver's --steps 20 --warmup 5
 #   legs      the other single-GPU BASELINE configs as their own bench lines (C3's shard, C4)
 #   sweep     kernel sweep: kinds x {random, controller} at SWEEP_N (default "65536 131072") -> sweep.md
-#             (SWEEP_TUNE="lean=0" adds rmav_set_tuning overrides; SWEEP_TAG names the output: sweep$SWEEP_TAG.md)
+#             (SWEEP_TUNE="split=0" adds rmav_set_tuning overrides; SWEEP_TAG names the output: sweep$SWEEP_TAG.md)
 #   steplat   tools/step_latency.py (single-step launch latency by feature subset)
 #   vecenv    bench.py's vecenv / gym1 legs only
 #   sq        SQ instruction / wait counters of the default bench command (EXTRA= adds bench arguments)
