@@ -152,15 +152,20 @@ int pick_store_policy(rmav_handle h, const RolloutArgs &a, bool split) {
 // workgroup, 256 workgroups - and loses as soon as it does not (a second round of workgroups, or pairs capped by the
 // 1024-thread / 160 KiB-LDS limits).  So the rule is capacity, not a tuned constant: two wavefronts iff
 // N <= 16 384 x (pairs that fit one workgroup for this kind and action source).
-template <int K, bool DRAWS> constexpr int split_pairs_max() {
-    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * split_words_per_pair<K, DRAWS ? ACT_RANDOM_SPLIT : ACT_CONTROLLER_SPLIT>()));
-    constexpr int cap = split_group_cap<K, DRAWS>();   // threads / registers (rmav_kernels.hpp)
+template <int K, int SMODE> constexpr int split_pairs_max() {   // SMODE: ACT_RANDOM_SPLIT | ACT_CONTROLLER_SPLIT | ACT_BUFFER_SPLIT
+    constexpr int by_lds = (int)((160u << 10) / (sizeof(float) * split_words_per_pair<K, SMODE>()));
+    constexpr int cap = split_group_cap<K, split_feeds_actions(SMODE)>();   // threads / registers (rmav_kernels.hpp)
     return by_lds < cap ? by_lds : cap;
 }
-constexpr int kSplitPairsRandom[4] = {split_pairs_max<QUAD2D, true>(), split_pairs_max<QUAD2D_SL, true>(),
-                                      split_pairs_max<QUAD3D, true>(), split_pairs_max<QUAD3D_SL, true>()};
-constexpr int kSplitPairsController[4] = {split_pairs_max<QUAD2D, false>(), split_pairs_max<QUAD2D_SL, false>(),
-                                          split_pairs_max<QUAD3D, false>(), split_pairs_max<QUAD3D_SL, false>()};
+#define RMAV_PAIRS(SMODE) {split_pairs_max<QUAD2D, SMODE>(), split_pairs_max<QUAD2D_SL, SMODE>(), split_pairs_max<QUAD3D, SMODE>(), split_pairs_max<QUAD3D_SL, SMODE>()}
+constexpr int kSplitPairsRandom[4] = RMAV_PAIRS(ACT_RANDOM_SPLIT);
+constexpr int kSplitPairsController[4] = RMAV_PAIRS(ACT_CONTROLLER_SPLIT);
+constexpr int kSplitPairsBuffer[4] = RMAV_PAIRS(ACT_BUFFER_SPLIT);
+#undef RMAV_PAIRS
+// pairs of one workgroup by the public action mode
+inline const int *split_pairs_of(int action_mode) {
+    return action_mode == RMAV_ACT_CONTROLLER ? kSplitPairsController : action_mode == RMAV_ACT_BUFFER ? kSplitPairsBuffer : kSplitPairsRandom;
+}
 constexpr int64_t kEnvsPerCuSlot = 16384;   // 256 CUs x 64 envs: one pair per CU
 constexpr bool kSliceByDefault = false;     // sliced two-wavefront launches beyond the capacity: measured, see DESIGN.md
 
@@ -177,7 +182,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
         // within 1024 threads and the CU's 160 KiB of LDS.  RMAV_TUNE_SPLIT_GROUP = 1..8 overrides.
         constexpr size_t lds_per_pair = sizeof(float) * split_words_per_pair<K, MODE>();
         const int forced = h->tune[RMAV_TUNE_SPLIT_GROUP];
-        constexpr int g_max = split_pairs_max<K, split_feeds_actions(MODE)>();
+        constexpr int g_max = split_pairs_max<K, MODE>();
         const int64_t count = a.slice_count ? (int64_t)a.slice_count : h->n;   // envs of this launch
         // Round 3 (profiles/r03/pairs_per_workgroup.md): one s_barrier synchronises ALL pairs of a workgroup, so every pair
         // pays for the slowest one's reset path each step.  Where the step time is the integrator's latency (the 2-D kinds,
@@ -212,7 +217,7 @@ int launch_rollout_kms(rmav_handle h, const RolloutArgs &a_in) {
 // RMAV_TUNE_SPLIT = 0 | 1 overrides the rule.
 // Batches beyond that capacity can still run on the two-wavefront kernel as a sequence of launches over balanced
 // slices of the env range, each one workgroup per CU (`slices` > 1): see launch_rollout_km.  RMAV_TUNE_SLICE = 0 | 1 overrides.
-bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, bool random_actions) {
+bool use_split(rmav_handle h, const RolloutArgs &a, int action_mode, int *slices, bool random_actions) {
     const int forced = h->tune[RMAV_TUNE_SPLIT], slice_forced = h->tune[RMAV_TUNE_SLICE];
     *slices = 1;
     if (h->chunk > 0) {   // rmav_rollout_chunked: one two-wavefront launch per chunk, whatever the other rules say
@@ -221,7 +226,7 @@ bool use_split(rmav_handle h, const RolloutArgs &a, bool draws, int *slices, boo
     }
     // the two-wavefront kernel also wins for short launches (2 .. 7 steps: -15 .. -30 %, measured)
     if (a.n_steps < 2 || h->kind > RMAV_QUAD3D_SL) return false;
-    const int64_t cap = kEnvsPerCuSlot * (draws ? kSplitPairsRandom : kSplitPairsController)[h->kind];
+    const int64_t cap = kEnvsPerCuSlot * split_pairs_of(action_mode)[h->kind];
     if (forced == 0) return false;
     if (h->n <= cap) return true;
     // Two rounds of the two-wavefront kernel - two launches over balanced halves of the env range - beat one launch of the
@@ -245,7 +250,7 @@ int launch_rollout_km(rmav_handle h, const RolloutArgs &a) {
         if constexpr ((MODE == ACT_RANDOM || MODE == ACT_CONTROLLER || MODE == ACT_BUFFER) && K != REINMAV) {
             constexpr int SMODE = (MODE == ACT_RANDOM) ? ACT_RANDOM_SPLIT : (MODE == ACT_BUFFER) ? ACT_BUFFER_SPLIT : ACT_CONTROLLER_SPLIT;
             int slices = 1;
-            if (use_split(h, a, MODE != ACT_CONTROLLER, &slices, MODE == ACT_RANDOM)) {
+            if (use_split(h, a, MODE == ACT_CONTROLLER ? RMAV_ACT_CONTROLLER : MODE == ACT_BUFFER ? RMAV_ACT_BUFFER : RMAV_ACT_RANDOM, &slices, MODE == ACT_RANDOM)) {
                 // balanced slices, each a multiple of 64 envs
                 const int64_t per = h->chunk > 0 ? h->chunk : slices > 1 ? (((h->n + slices - 1) / slices + 63) / 64) * 64 : h->n;
                 RolloutArgs ap = a;
@@ -996,7 +1001,7 @@ int rmav_rollout_chunked(rmav_handle h, int32_t n_steps, int action_mode, const 
         return rollout_impl(h, n_steps, action_mode, actions_in, actions_out, obs_out, rew_out, done_out, nullptr, RMAV_DEVICE, RMAV_SOA, 1,
                             chunk_envs > h->n ? chunk_envs : 0);
     if (h->kind > RMAV_QUAD3D_SL) return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts are for the quadrotor kinds");
-    const int64_t cap = kEnvsPerCuSlot * (action_mode == RMAV_ACT_CONTROLLER ? kSplitPairsController : kSplitPairsRandom)[h->kind];
+    const int64_t cap = kEnvsPerCuSlot * split_pairs_of(action_mode)[h->kind];
     if (n_steps < 2 || chunk_envs > cap)
         return rmav_fail(RMAV_ERR_INVALID, "chunk-major rollouts need n_steps >= 2 and chunk_envs <= %lld for this kind and action source", (long long)cap);
     if (actions_out && action_mode == RMAV_ACT_BUFFER)   // (rollout_impl's echo copy is sized for the plain layout)

@@ -51,8 +51,14 @@ enum : int { ACT_BUFFER = 0, ACT_RANDOM = 1, ACT_CONTROLLER = 2, ACT_POLICY = 3,
 constexpr bool is_mfma_policy(int mode) { return mode == ACT_POLICY_BF16 || mode == ACT_POLICY_F32M; }
 constexpr bool is_policy(int mode) { return mode == ACT_POLICY || is_mfma_policy(mode); }
 constexpr bool is_split(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_CONTROLLER_SPLIT || mode == ACT_BUFFER_SPLIT; }
-// split modes whose memory wavefront hands actions TO the integrator (drawn, or fetched from the caller's buffer)
-constexpr bool split_feeds_actions(int mode) { return mode == ACT_RANDOM_SPLIT || mode == ACT_BUFFER_SPLIT; }
+// split mode whose memory wavefront hands actions TO the integrator (it draws them).  The caller's actions (ACT_BUFFER_SPLIT) were
+// fetched by the memory wavefront as well until round 6: on gfx950 loads and stores share ONE counter (vmcnt) and return out of order
+// with respect to each other, so a wavefront that both prefetches and stores can only wait for a load with vmcnt(0) - i.e. for every
+// outstanding trajectory store (profiles/r06/kernel_sweep.md: 59 % of the wavefronts' cycles in waits).  Now the INTEGRATOR fetches
+// them - it has no store in its step loop any more: its rare termination stores moved to the memory wavefront - in bursts of
+// buf_prefetch<NA>() steps through a private LDS ring (split_self_fetch).
+constexpr bool split_feeds_actions(int mode) { return mode == ACT_RANDOM_SPLIT; }
+constexpr bool split_self_fetch(int mode) { return mode == ACT_BUFFER_SPLIT; }
 constexpr bool is_buffer(int mode) { return mode == ACT_BUFFER || mode == ACT_BUFFER_CTRL; }
 // kernels whose first workgroup publishes "begun" for an armed statistics exchange (see the top of k_rollout)
 constexpr bool publishes_start(int mode) { return mode != ACT_CONTROLLER_SPLIT; }
@@ -108,9 +114,16 @@ template <int NS, int NA, bool DRAWS = true> struct SplitTile {
 // barrier for all pairs; 97 % of its steps have a terminating lane somewhere): 2-D kinds at 65 536 envs +5 %.  So only there.
 // (The random- and caller-action 3-D slung-load integrators sit at 127-131 registers with it: LDS as well; measured equal.)
 template <int K, int MODE> constexpr bool spare_in_lds() { return K == QUAD3D_SL && is_split(MODE); }
+#ifndef RMAV_BUF_PREFETCH
+#define RMAV_BUF_PREFETCH 4   // env-steps per burst of the integrator's action fetch (ACT_BUFFER_SPLIT); a power of two
+#endif
+// ... and twice that for the 2-action kinds, whose steps are half as long
+template <int NA> constexpr int buf_prefetch() { return NA <= 2 ? 2 * RMAV_BUF_PREFETCH : RMAV_BUF_PREFETCH; }
+// LDS words of the integrator's private action ring [buf_prefetch][NA][lane] (ACT_BUFFER_SPLIT), after the tiles and spares of all pairs
+template <int NA> constexpr int buf_ring_words() { return buf_prefetch<NA>() * NA * 64; }
 template <int K, int MODE> constexpr int split_words_per_pair() {
     using T = SplitTile<Dims<K>::NS, Dims<K>::NA, split_feeds_actions(MODE)>;
-    return T::WORDS + (spare_in_lds<K, MODE>() ? T::SPARE : 0);
+    return T::WORDS + (spare_in_lds<K, MODE>() ? T::SPARE : 0) + (split_self_fetch(MODE) ? buf_ring_words<Dims<K>::NA>() : 0);
 }
 // F_LEAN (set by the host for the two-wavefront kernels): feature-major trajectories whose every array spans < 4 GiB, so the
 // memory wavefront can address them with ONE descriptor per array and a 32-bit scalar step offset (see the lean drain below)
@@ -283,12 +296,7 @@ __device__ __forceinline__ void buf_st_aux(rsrc_t r, uint32_t voff, uint32_t sof
 // interleaved repetitions): random-action rollouts 0-8 % slower, controller-driven ones 0-4 % faster; and the memory
 // system absorbs 16-byte and 4-byte stores at the same rate (tools/micro/store_patterns.hip).  -DRMAV_WIDE_DRAIN=1
 // builds it; both drains pass the parity suite bit for bit.
-#ifndef RMAV_BUF_PREFETCH
-#define RMAV_BUF_PREFETCH 4   // hand-overs the memory wavefront fetches the caller's actions ahead (ACT_BUFFER_SPLIT)
-#endif
-// ... and twice that for the 2-action kinds, whose steps are half as long (65 536 envs quadrotor2d: 38.6 -> 36.6 us per 64-step
-// launch; the 3-D kinds measure the same at 4, 8 and 12)
-template <int NA> constexpr int buf_prefetch() { return NA <= 2 ? 2 * RMAV_BUF_PREFETCH : RMAV_BUF_PREFETCH; }
+
 #ifndef RMAV_WIDE_DRAIN
 #define RMAV_WIDE_DRAIN 0
 #endif
@@ -434,6 +442,35 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 const uint32_t e = 64u * q + lane;
                 aos_rd[q] = (e / NS) * ST_::OBS_STRIDE + (e % NS);
             }
+            // ACT_BUFFER_SPLIT: this wavefront also writes the last-episode statistics when an env's episode ends (the integrator's
+            // only stores inside its step loop - it must not have any, see split_self_fetch): the same running sums from the same
+            // rewards in the same order, so the same bits
+            [[maybe_unused]] float er_m = 0.0f;
+            [[maybe_unused]] int32_t el_m = 0;
+            if constexpr (split_self_fetch(MODE)) {
+                if (track) {
+                    er_m = buf_ld(make_rsrc(a.ep_ret), off, 0);
+                    el_m = (int32_t)(ep_clock0(a) - rec_ld_word(make_rsrc(a.rec), li, 2));
+                    // wait for the two loads HERE, before the first store is in flight: left to the first use inside the drain loop the
+                    // compiler's s_waitcnt vmcnt(0) would sit in the loop and wait for every outstanding trajectory store, every step
+                    asm volatile("" : "+v"(er_m), "+v"(el_m));
+                }
+            }
+            static_assert(!(RMAV_WIDE_DRAIN && split_self_fetch(MODE)), "the wide drain does not carry the episode statistics");
+            auto episode_end = [&](float rw, float dn) {
+                if constexpr (split_self_fetch(MODE)) {
+                    if (track) {
+                        er_m += rw;
+                        el_m += 1;
+                        if (dn != 0.0f) {
+                            buf_st(make_rsrc(a.last_ret), off, 0, er_m);
+                            rec_st_last_len(make_rsrc(a.rec), li, el_m);
+                            er_m = 0.0f;
+                            el_m = 0;
+                        }
+                    }
+                }
+            };
             auto fill = [&](int32_t c) {   // actions of chunk c: draw, hand over, write the action trajectory
                 float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
 #pragma unroll
@@ -548,6 +585,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                         if (a.done_out)
                             __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(row[ST_::DONE] != 0.0f ? 1 : 0),
                                                                  make_rsrc(a.done_out + (int64_t)k * tn), li, 0, 0);
+                        episode_end(row[ST_::REW], row[ST_::DONE]);
                     }
                 }
             };
@@ -586,43 +624,9 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                     for (int q = 0; q < NS; ++q) buf_st_aux<AUX>(rO, voff[q], (uint32_t)k * sO, o[q]);
                     buf_st_aux<AUX>(rR, off, (uint32_t)k * sR, rw);
                     __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(dn != 0.0f ? 1 : 0), rD, li, (uint32_t)k * sD, 0);
+                    episode_end(rw, dn);
                 };
-                if constexpr (MODE == ACT_BUFFER_SPLIT) {
-                    constexpr int D = buf_prefetch<NA>();
-                    const rsrc_t rI = make_rsrc(a.act_in);
-                    float pre[D][NA];
-                    auto issue = [&](int32_t k, float (&dst)[NA]) {
-                        if (k < T) {
-#pragma unroll
-                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(rI, voff[q], (uint32_t)k * sA);
-                        }
-                    };
-                    auto put = [&](int32_t c, const float (&src)[NA]) {
-                        float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
-#pragma unroll
-                        for (int q = 0; q < NA; ++q) buf[q * 64] = src[q];
-                    };
-#pragma unroll
-                    for (int d = 0; d < D; ++d) issue(d, pre[d]);
-                    put(0, pre[0]);
-                    issue(D, pre[0]);
-                    put(1, pre[1 % D]);
-                    issue(D + 1, pre[1 % D]);
-                    __syncthreads();                               // B0
-                    __syncthreads();                               // B0x
-                    for (int32_t cb = 1; cb < nc; cb += D) {
-#pragma unroll
-                        for (int d = 0; d < D; ++d) {              // step c + 1 = cb + d + 1 lives in slot (2 + d) % D: static register indices
-                            const int32_t c = cb + d;
-                            if (c < nc) {                          // wave- and workgroup-uniform
-                                put(c + 1, pre[(2 + d) % D]);
-                                issue(c + 1 + D, pre[(2 + d) % D]);
-                                if (c >= 2) drain_l(c - 2);
-                                __syncthreads();                   // Bc
-                            }
-                        }
-                    }
-                } else {
+                {
                     [[maybe_unused]] uint32_t blk[4] = {0u, 0u, 0u, 0u};   // 2-action kinds: the Philox block of the current pair of steps
                     [[maybe_unused]] bool blk_valid = false;
                     auto fill_l = [&](int32_t k) {   // actions of step k: draw, hand over, write the action trajectory
@@ -702,52 +706,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 drain_l(nc - 1);
                 return;
             }
-            if constexpr (MODE == ACT_BUFFER_SPLIT) {
-                // The caller's actions come from HBM: fetched D hand-overs ahead into registers (a load issued one hand-over
-                // ahead exposed its ~1 us round trip on every env-step: 71 us per 64-step launch at 65 536 envs instead of 41).
-                static_assert(CH == 1, "one env-step per hand-over");
-                constexpr int D = buf_prefetch<NA>();
-                float pre[D][NA];
-                auto issue = [&](int32_t k, float (&dst)[NA]) {
-                    if (k < T) {
-                        const float *src_step = a.act_in + (int64_t)k * NA * tn;
-                        if (aos) {
-                            const float *src = src_step + (int64_t)li * NA;
-#pragma unroll
-                            for (int q = 0; q < NA; ++q) dst[q] = src[q];
-                        } else {
-                            const rsrc_t ri = make_rsrc(src_step);
-#pragma unroll
-                            for (int q = 0; q < NA; ++q) dst[q] = buf_ld(ri, off, (uint32_t)q * tcol);
-                        }
-                    }
-                };
-                auto put = [&](int32_t c, const float (&src)[NA]) {
-                    float *buf = lds_p + (c & 1) * ST_::A_HALF + lane;
-#pragma unroll
-                    for (int q = 0; q < NA; ++q) buf[q * 64] = src[q];
-                };
-#pragma unroll
-                for (int d = 0; d < D; ++d) issue(d, pre[d]);
-                put(0, pre[0]);
-                issue(D, pre[0]);
-                put(1, pre[1 % D]);
-                issue(D + 1, pre[1 % D]);
-                __syncthreads();                               // B0
-                __syncthreads();                               // B0x
-                for (int32_t cb = 1; cb < nc; cb += D) {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {              // step c + 1 = cb + d + 1 lives in slot (2 + d) % D: static register indices
-                        const int32_t c = cb + d;
-                        if (c < nc) {                          // wave- and workgroup-uniform
-                            put(c + 1, pre[(2 + d) % D]);
-                            issue(c + 1 + D, pre[(2 + d) % D]);
-                            if (c >= 2) drain(c - 2);
-                            __syncthreads();                   // Bc
-                        }
-                    }
-                }
-            } else {
+            {
                 if constexpr (DRAWS) {
                     fill(0);
                     if (nc >= 2) fill(1);
@@ -918,6 +877,35 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             }
         };
         if constexpr (is_buffer(MODE)) load_actions(act_in, act_pre);
+        // ACT_BUFFER_SPLIT: the caller's actions in bursts of D steps.  ring_fetch(k0) issues the loads of steps k0 .. k0 + D - 1 into
+        // registers; D steps later ring_put() parks them in this lane's column of a private LDS ring (read back by this lane only: no
+        // barrier) and the next burst is issued - so every load has D steps (~2 - 5 us) to arrive, and the only vmcnt wait of the
+        // loop sees loads alone (this wavefront stores nothing inside the loop).
+        [[maybe_unused]] float ring_pre[split_self_fetch(MODE) ? buf_prefetch<NA>() : 1][NA];
+        [[maybe_unused]] float *lds_ring = nullptr;
+        [[maybe_unused]] auto ring_fetch = [&](int32_t k0) {
+            if constexpr (split_self_fetch(MODE)) {
+#pragma unroll
+                for (int d = 0; d < buf_prefetch<NA>(); ++d)
+                    if (k0 + d < a.n_steps) load_actions(a.act_in + (int64_t)(k0 + d) * NA * tn, ring_pre[d]);
+            }
+        };
+        [[maybe_unused]] auto ring_put = [&]() {
+            if constexpr (split_self_fetch(MODE)) {
+#pragma unroll
+                for (int d = 0; d < buf_prefetch<NA>(); ++d)
+#pragma unroll
+                    for (int c = 0; c < NA; ++c) lds_ring[(d * NA + c) * 64] = ring_pre[d][c];
+            }
+        };
+        if constexpr (split_self_fetch(MODE)) {
+            using STB = SplitTile<NS, NA, DRAWS>;
+            lds_ring = lds_w + split_g * (STB::WORDS + (spare_in_lds<K, MODE>() ? STB::SPARE : 0)) +
+                       (uint32_t)__builtin_amdgcn_readfirstlane(split_local >> 6) * buf_ring_words<NA>() + (threadIdx.x & 63u);
+            ring_fetch(0);
+            ring_put();
+            ring_fetch(buf_prefetch<NA>());
+        }
         // two-wavefront modes whose memory wavefront supplies the actions: A(k + 1) is fetched from the hand-over tile while
         // step k is integrated (see the protocol above)
         [[maybe_unused]] float act_nx[NA];
@@ -991,6 +979,20 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
             } else if constexpr (MODE == ACT_CONTROLLER_SPLIT) {
                 if ((k % CH) == 0) __syncthreads();   // B(k / chunk): the output tile swaps halves
                 env_control<K>(s, pc, act);
+            } else if constexpr (split_self_fetch(MODE)) {
+                if ((k % CH) == 0) __syncthreads();   // B(k / chunk), as the controller-driven integrator
+                constexpr int D = buf_prefetch<NA>();
+                static_assert((D & (D - 1)) == 0, "burst length: a power of two");
+                const int32_t slot = k & (D - 1);
+                if (slot == 0 && k > 0) {   // wave-uniform.  Burst boundary: the loads issued D steps ago go into the ring, the next D are issued
+                    ring_put();
+                    ring_fetch(k + D);
+                }
+                // (read at the top of its own step: fetching it one step ahead, as the random-action integrator does with its tile,
+                // measured the same and costs the slung-load integrators the four registers they do not have)
+                const float *rb = lds_ring + slot * (NA * 64);
+#pragma unroll
+                for (int c = 0; c < NA; ++c) act[c] = rb[c * 64];
             } else if constexpr (K == REINMAV) {
 #pragma unroll
                 for (int c = 0; c < NA; ++c) act[c] = 0.0f;   // the built-in controller runs inside every sub-step
@@ -1057,8 +1059,10 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 }
                 if (__ballot(done) != 0) {
                     if (track && done) {
-                        buf_st(make_rsrc(a.last_ret), off, 0, er);
-                        rec_st_last_len(make_rsrc(a.rec), li, el);
+                        if constexpr (!split_self_fetch(MODE)) {   // (ACT_BUFFER_SPLIT: the memory wavefront writes them)
+                            buf_st(make_rsrc(a.last_ret), off, 0, er);
+                            rec_st_last_len(make_rsrc(a.rec), li, el);
+                        }
                         if (valid && !(HALF && (threadIdx.x & 32u))) {   // (the second copy of an env does not count)
                             fin_n += 1;
                             fin_len += (unsigned int)el;
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__((rollout_threads_max<K, MODE>())) void k_rollout(co
                 done_out += tn;
             }
         }
-        if constexpr (MODE == ACT_CONTROLLER_SPLIT) __syncthreads();   // B(nc): the last step's outputs are in LDS
+        if constexpr (MODE == ACT_CONTROLLER_SPLIT || split_self_fetch(MODE)) __syncthreads();   // B(nc): the last step's outputs are in LDS
 
         if constexpr (is_mfma_policy(MODE)) {   // bootstrap value of the state the rollout ends in
             float x[16], mean[4], val0;
