@@ -10,6 +10,8 @@
 //          3 = 1 + the same three dwords loaded LAZILY in ending lanes, five scattered dword stores (k_step beyond)
 //          4 = 1 + lazy ONE 32-byte record per env {sbd, reset count, start, last return, last length, pad}: two b128 loads, two b128 stores (a full sector)
 //          5 = 1 + lazy ONE 16-byte record {sbd, reset count, start, last length}: one b128 load, one b128 store + one dword store (last return)
+//          6 = 1 + an EAGER 4-byte "hot" word per env (reset count + sbd-is-None: all the reward and the reset draw need) and the 16-byte record loaded
+//              lazily OFF the critical path: nothing but the record's own store waits for it
 // Reports us per launch and the fraction of 8 TB/s on the 101 algorithmic bytes, like bench.py's `legs.step*`.
 // build: hipcc --offload-arch=gfx950 -O3 -o tools/micro/_build/step_shape tools/micro/step_shape.hip
 #include <hip/hip_runtime.h>
@@ -59,6 +61,7 @@ __global__ __launch_bounds__(256) void k_shape(const Args a) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) x[t][c] = ld(rx, off, c * col);
         }
+        if (BK == 6) x[t][0] = ld(rx, off, 0);
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(256) void k_shape(const Args a) {
             q1 = a.rec[2 * (size_t)i + 1];
             x[t][0] = __builtin_bit_cast(float, q0.x); x[t][1] = __builtin_bit_cast(float, q0.y); x[t][2] = __builtin_bit_cast(float, q0.z);
         }
+        if (BK == 6 && fin) q0 = a.rec[(size_t)i];   // lazily; only the record's own store below uses it
         if (BK == 5 && fin) {
             q0 = a.rec[(size_t)i];
             x[t][0] = __builtin_bit_cast(float, q0.x); x[t][1] = __builtin_bit_cast(float, q0.y); x[t][2] = __builtin_bit_cast(float, q0.z);
@@ -111,6 +115,10 @@ __global__ __launch_bounds__(256) void k_shape(const Args a) {
                     q0.x += 1; q0.y += 1; q0.z += 1; q0.w = __builtin_bit_cast(uint32_t, l0); q1.x = __builtin_bit_cast(uint32_t, l1);
                     a.rec[2 * (size_t)i] = q0; a.rec[2 * (size_t)i + 1] = q1;
                 }
+                if (BK == 6) {
+                    st(rx, off, 0, x[t][0] + 1.f, 0);   // the hot word
+                    st(rx, off, 3 * col, l0, 0);
+                }
                 if (BK == 5) {
                     q0.x += 1; q0.y += 1; q0.z += 1; q0.w = __builtin_bit_cast(uint32_t, l1);
                     a.rec[(size_t)i] = q0;
@@ -119,6 +127,10 @@ __global__ __launch_bounds__(256) void k_shape(const Args a) {
             }
 #pragma unroll
             for (int c = 0; c < 10; ++c) st(rs, off, c * col, s[t][c] + r * 1e-30f, a.nt);
+            if (BK == 6 && fin) {
+                q0.x += 1; q0.y += 1; q0.z += 1; q0.w = __builtin_bit_cast(uint32_t, l1 + __builtin_bit_cast(float, q0.z));
+                a.rec[(size_t)i] = q0;
+            }
         }
     }
 }
@@ -163,6 +175,7 @@ template <int TILES, int CH> void all_bk(uint32_t n, int block, int nt) {
     run<TILES, 3, CH>(n, block, nt, "lazy soa");
     run<TILES, 4, CH>(n, block, nt, "lazy rec32");
     run<TILES, 5, CH>(n, block, nt, "lazy rec16");
+    run<TILES, 6, CH>(n, block, nt, "hot word + late rec16");
 }
 int main(int argc, char **argv) {
     const bool full = argc > 1 && !strcmp(argv[1], "full");
