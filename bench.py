@@ -45,7 +45,7 @@ secondary leg in full, device state, the CPU thread scan, calibration - goes to 
 ``gpurun_out/bench_detail.json``), named by the line's ``detail`` key; nothing else is printed to stdout, and stderr
 stays quiet unless something fails.  (Round 4's single 22 KB line could not be recovered from the driver's 8 KB tail.)
 Default ``--secondary`` = the per-step kernel at three batch sizes, BASELINE configs[2]'s per-GPU shard (plain and chunk-major
-trajectories) and configs[3] (~1 s each), and the sustained stretch (11 s of the headline launches, so that an outside GPU-busy
+trajectories), configs[3] and configs[4]'s per-GPU shard with the policy in-kernel (~1 s each), and the sustained stretch (11 s of the headline launches, so that an outside GPU-busy
 sampler cannot miss it); with the 10 s + 3 s CPU baselines the default run takes ~30 s.  ``--secondary all`` adds the
 policy-in-kernel rollouts, ReinmavEnv, the gym-shaped env and the VecEnv (~25 s more).
 """
@@ -436,7 +436,7 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=11.0,
                     help="length of the `sustained` leg: the headline launches back to back, long enough for an outside GPU-busy sampler "
                          "with a 5 s period to see at least two busy samples")
-    ap.add_argument("--secondary", default="step,sustained,cpu_mt,c3_shard,c4",
+    ap.add_argument("--secondary", default="step,sustained,cpu_mt,c3_shard,c4,c5",
                     help="comma list of the other measurements (single process only): step (k_step at 65 536 / 262 144 / 1 048 576 envs), "
                          "sustained, in_place, c3_shard, c4, c4_pe, reinmav, gym1, vecenv, policy, cpu_mt (OpenMP CPU baseline), cpu_py; "
                          "'all' = every one of them (~25 s more)")
@@ -650,6 +650,15 @@ def main():
         all_legs = "all" in sec
         if "all" in sec:
             sec = {"in_place", "step", "c3_shard", "c4", "c4_pe", "reinmav", "gym1", "vecenv", "policy", "sustained", "cpu_mt", "cpu_py"}
+        # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
+        # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
+        with DeviceSampler(dev.index or 0) as sampler:
+            wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
+                                                               prewarm_ms=args.prewarm_ms)
+        device_state = sampler.summary()
+        # (round 6: the headline is measured FIRST, the long sustained stretch LAST - the other configs' legs used to run ahead of the
+        #  headline and left the package at its power limit: the 20 timed launches of the driver's command came out 3 - 8 % below the
+        #  sustained rate; and C4's fp64 kernel measured right after 11 s at the power limit loses 15 %)
         if "step" in sec or "in_place" in sec:
             if args.mode == "rollout" and "step" in sec:
                 # the per-step kernel at the headline's batch, and where it is not launch-bound (262 144 / 1 048 576 envs)
@@ -684,12 +693,6 @@ def main():
                     other["reinmav"] = bench_reinmav(g, torch, dev, cpu_seconds=min(3.0, args.cpu_seconds))
             except Exception as e:  # pragma: no cover
                 other["legs_error"] = repr(e)
-        # the headline measurement: W untimed launches, then exactly K timed ones.  (The first ~5 ms of GPU work
-        # after idle run ~15 % slower on these boxes, so the defaults are sized well past that.)
-        with DeviceSampler(dev.index or 0) as sampler:
-            wall, kernel_ms, per_launch, R, gathered = measure(args.mode, args.chunk, args.steps, args.warmup, args.in_place,
-                                                               prewarm_ms=args.prewarm_ms)
-        device_state = sampler.summary()
         if single and "sustained" in sec and args.mode == "rollout":
             # --sustained-seconds (11 s) of the headline launches back to back (outside the K timed ones): a stretch long enough for
             # clocks and the package power limit to settle, and for an outside busy sampler with a 5 s period to see the GPU at work
@@ -766,6 +769,8 @@ def main():
                 other["vecenv"] = bench_vecenv(dev, n)
             if "policy" in sec and kind != "reinmav":
                 other["policy_rollout"] = bench_policy(dev, kind, n)
+            elif "c5" in sec and kind == "quad3d":   # configs[4]'s per-GPU shard with the two default actors only (~1 s): the driver's line carries C5 too
+                other["policy_rollout"] = bench_policy(dev, kind, 65536, actors=("f16_mfma", "f16_shared"))
                 if args.cpu_seconds > 0:
                     other["policy_rollout"]["cpu_baseline"] = cpu_policy_baseline(kind, min(3.0, args.cpu_seconds))
         except Exception as e:  # pragma: no cover - never lose the headline line to a secondary leg
@@ -1090,7 +1095,7 @@ def bench_vecenv(dev, n: int, iters: int = 3000):
     return out
 
 
-def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
+def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60, actors=None):
     """BASELINE configs[4] (C5)'s per-GPU shape: 65 536 envs x 32-step PPO2-style rollouts with the Gaussian MLP policy
     and value net evaluated inside the rollout kernel (rmav_rollout_policy), plus the GAE pass over the result."""
     import torch
@@ -1107,7 +1112,7 @@ def bench_policy(dev, kind: str, n: int, T: int = 32, iters: int = 60):
     # bf16_1w: round 3's kernel (one wavefront per 64 envs); bf16_mfma / f16_mfma: (actor, critic) wavefront pairs (rmav_policy_pair.hpp)
     # f16_shared: a DIFFERENT architecture - one 2x64 trunk with a mean head and a value head (baselines' value_network = 'shared': what
     # ppo2 builds for gym_reinmav's native env type) - half the activations of the two-net policy the other rows evaluate
-    for actor in ("fp32_valu", "fp32_mfma", "bf16_1w", "bf16_mfma", "f16_mfma", "f16_shared"):
+    for actor in (actors or ("fp32_valu", "fp32_mfma", "bf16_1w", "bf16_mfma", "f16_mfma", "f16_shared")):
         torch.manual_seed(0)
         env = g.BatchedQuadrotor(kind, n, device=dev.index, seed=0, auto_reset=True, track_episodes=True)
         if actor == "bf16_1w":

@@ -58,6 +58,7 @@ def test_bench_driver_command_line_is_compact(built, tmp_path):
     legs = j["legs"]
     for k in ("step", "step_262144", "step_1048576", "sustained", "c3_shard", "c3_shard_chunked", "c4"):   # configs[2]'s shard and configs[3] ride along
         assert 0.0 < legs[k]["frac"] <= 1.0, (k, legs[k])
+    assert legs["policy_rollout"]["f16_shared"]["value"] > legs["policy_rollout"]["f16_mfma"]["value"] > 0     # configs[4]'s per-GPU shard rides along too
     assert j["value_sustained"] == pytest.approx(legs["sustained"]["value"], rel=1e-3)
     assert len(json.dumps(j, separators=(",", ":"))) < 4000 and el < 60.0      # (~30 s: 10 s + 3 s of CPU baselines, 11 s sustained)
     mt = j["cpu_mt"]
