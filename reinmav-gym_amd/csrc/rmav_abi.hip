@@ -331,8 +331,15 @@ template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctr
     const int st = step_store(h), bs = step_block(h);
     const bool lazy = step_lazy(h);
     const dim3 grid((unsigned)((h->n + bs - 1) / bs));
-#define RMAV_STEP(LAZY, ST) hipLaunchKernelGGL((k_step<K, false, LAZY, ST>), grid, dim3(bs), 0, h->stream, a, p, pc)
-    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid, dim3(bs), 0, h->stream, a, p, pc);
+    const bool big = h->n >= 786432;   // no argument preloading for the big batches (k_step_big in rmav_kernels.hpp says why)
+    // (the leading scalars are what the kernel's first loads need: preloaded into scalar registers, see StepHot in rmav_kernels.hpp)
+#define RMAV_STEP_ARGS a.state, a.n, a.act_in, a.pitch, (uint32_t)bs, a.flags, a.ep_ret, a.rec, a, p, pc
+#define RMAV_STEP(LAZY, ST)                                                                                           \
+    do {                                                                                                              \
+        if (big) hipLaunchKernelGGL((k_step_big<K, LAZY, ST>), grid, dim3(bs), 0, h->stream, a, p, pc);               \
+        else hipLaunchKernelGGL((k_step<K, false, LAZY, ST>), grid, dim3(bs), 0, h->stream, RMAV_STEP_ARGS);          \
+    } while (0)
+    if (ctrl) hipLaunchKernelGGL((k_step<K, true>), grid, dim3(bs), 0, h->stream, RMAV_STEP_ARGS);
     else if (lazy && st == ST_STREAM) RMAV_STEP(true, ST_STREAM);
     else if (lazy && st == ST_WRITE_THROUGH) RMAV_STEP(true, ST_WRITE_THROUGH);
     else if (lazy) RMAV_STEP(true, ST_DEFAULT);
@@ -340,6 +347,7 @@ template <int K> int launch_step_k(rmav_handle h, const RolloutArgs &a, bool ctr
     else if (st == ST_STREAM) RMAV_STEP(false, ST_STREAM);
     else RMAV_STEP(false, ST_DEFAULT);
 #undef RMAV_STEP
+#undef RMAV_STEP_ARGS
     HIP_TRY(hipGetLastError());
     return RMAV_OK;
 }

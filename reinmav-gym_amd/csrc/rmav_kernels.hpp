@@ -1347,13 +1347,21 @@ __device__ __forceinline__ void reset_state_wave(uint64_t seed, uint64_t env_id_
 // 8 B per env-step less HBM-side traffic (the launch fetches 1.28 x its algorithmic bytes otherwise, of which these two
 // arrays are 0.08), but a dependent memory round trip on the critical path of every wavefront that has a finishing lane
 // (57 % of them), in a kernel whose whole duration is ~1.5 round trips above the launch floor.  profiles/r03/step_lazy_ab.md.
-template <int K, bool CTRL, bool LAZY = false, int ST = ST_DEFAULT>
-__global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const typename Env<K>::P p_shared,
-                                                 const ParamsT<double> pc_shared) {
+// What the first loads of k_step need, as LEADING scalar kernel arguments (16 dwords): with -mllvm -amdgpu-kernarg-preload-count=16
+// (Makefile) the command processor puts them into scalar registers when it launches a wavefront, so the state / action loads issue
+// without first waiting for an s_load of the argument block - one scalar-cache round trip off the critical path of a launch that
+// lasts ~1.5 memory round trips (round 6; tools/micro/launch_floor.hip with and without the flag: 2.90 -> 2.72 us for a 14-load /
+// 11-store kernel at 65 536 threads).  Aggregates (RolloutArgs, the constants) cannot be preloaded and follow as before; the fields
+// duplicated here are read from these arguments only.
+struct StepHot {   // (documentation of the argument order; passed as separate scalars)
+    float *state; int64_t n; const float *act_in; int64_t pitch; uint32_t block, flags; float *ep_ret; EnvRec *rec;
+};
+template <int K, bool CTRL, bool LAZY, int ST>
+__device__ __forceinline__ void step_body(const RolloutArgs &a, const uint32_t block_pl, const typename Env<K>::P &p_shared, const ParamsT<double> &pc_shared) {
     static_assert(K != REINMAV, "ReinmavEnv steps go through k_rollout");
     constexpr int NS = Dims<K>::NS, NA = Dims<K>::NA;
     constexpr int AUX = StoreAux<ST>::value;   // cache policy of the per-env stores (RMAV_TUNE_STEP_STORE; measured in profiles/r04/step_store_policy.md)
-    const uint32_t gi = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gi = blockIdx.x * block_pl + threadIdx.x;
     const int64_t n = a.n;
     const bool valid = gi < (uint64_t)n;
     // lanes past the end of the batch are clones of env N-1 that store nothing: all 64 lanes of every wavefront
@@ -1543,6 +1551,31 @@ __global__ __launch_bounds__(kBlock) void k_step(const RolloutArgs a, const type
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every lane's output stores have been acknowledged
         if (gi == 0) __hip_atomic_store(a.done_flag, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// The two entry points of step_body.  k_step: the eager variant (below 786 432 envs, where a launch is latency-bound) with the
+// preloaded leading arguments (StepHot).  k_step_big: the lazy variant of the big batches WITHOUT them - there the command processor's
+// extra work per wavefront launch (16 384 wavefronts at 1 048 576 envs) costs more than the saved scalar load: same-box A/B
+// 21.7 -> 22.6 us with preloading, against 4.25 -> 3.93 us at 65 536 envs and 6.32 -> 5.95 at 262 144 (profiles/r06/step_preload_ab.md).
+template <int K, bool CTRL, bool LAZY = false, int ST = ST_DEFAULT>
+__global__ __launch_bounds__(kBlock) void k_step(float *state_pl, int64_t n_pl, const float *act_pl, int64_t pitch_pl, uint32_t block_pl, uint32_t flags_pl,
+                                                 float *ep_ret_pl, EnvRec *rec_pl, const RolloutArgs a_in, const typename Env<K>::P p_shared,
+                                                 const ParamsT<double> pc_shared) {
+    // the preloaded copies replace the struct's fields (same values: launch_step_k fills both); every other field is still
+    // loaded from the argument block when it is first used
+    RolloutArgs a = a_in;
+    a.state = state_pl;
+    a.n = n_pl;
+    a.act_in = act_pl;
+    a.pitch = pitch_pl;
+    a.flags = flags_pl;
+    a.ep_ret = ep_ret_pl;
+    a.rec = rec_pl;
+    step_body<K, CTRL, LAZY, ST>(a, block_pl, p_shared, pc_shared);
+}
+template <int K, bool LAZY, int ST>
+__global__ __launch_bounds__(kBlock) void k_step_big(const RolloutArgs a, const typename Env<K>::P p_shared, const ParamsT<double> pc_shared) {
+    step_body<K, false, LAZY, ST>(a, blockDim.x, p_shared, pc_shared);
 }
 
 // reset() of every env
