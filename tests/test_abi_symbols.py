@@ -27,6 +27,19 @@ def test_every_declared_symbol_is_exported(built):
     assert sorted(A.PROTOTYPES) == names, "ctypes prototypes out of sync with the header"
 
 
+def test_tuning_keys_match_the_header():
+    """_abi.TUNE (what env.set_tuning / bench.py --tune name) is exactly enum rmav_tuning_key of include/rmav.h - nine keys since
+    round 6 (the keys of rejected variants were removed), numbered densely."""
+    from gym_reinmav_amd import _abi as A
+
+    txt = open(os.path.join(ROOT, "include", "rmav.h")).read()
+    body = txt[txt.index("enum rmav_tuning_key {"):]
+    body = body[:body.index("};")]
+    keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"RMAV_TUNE_([A-Z_]+)\s*=\s*(\d+)", body)}
+    count = keys.pop("count")
+    assert keys == A.TUNE and sorted(keys.values()) == list(range(count)) and count == 9
+
+
 def test_library_level_queries(built):
     from gym_reinmav_amd import _abi as A
 
