@@ -224,9 +224,51 @@ def make_reinmav():
     print("reinmav", {k: v.shape for k, v in out.items()}, os.path.getsize(path), "bytes")
 
 
+# self.g is a public attribute the reference reads on every call (quadrotor3d.py:47,96-99,162; quadrotor2d.py:46,88): the same
+# step / control cases with a TILTED gravity vector assigned to the env object - what rmav_params.g_vec carries (round 6)
+GRAVITY = {"quad2d": (1.25, -8.5), "quad2d_sl": (-0.75, -9.0), "quad3d": (1.25, -0.75, -8.5), "quad3d_sl": (-1.0, 0.5, -9.25)}
+
+
+def make_gravity():
+    out = {}
+    for kind in rh.KINDS:
+        rng = np.random.RandomState({"quad2d": 21, "quad2d_sl": 22, "quad3d": 23, "quad3d_sl": 24}[kind])
+        nS, nA = NS[kind], NA[kind]
+        lo, hi = BOX[kind]
+        n = 384
+        S = f32r(np.array([rng.uniform(-(1.0 if i % 2 == 0 else 2.5), (1.0 if i % 2 == 0 else 2.5), nS) for i in range(n)]))
+        A = f32r(np.array([rng.uniform(lo, hi, nA) for _ in range(n)]))
+        if kind in TETHER:   # keep clear of the tether switch: the branch there hangs on the last bit of a norm
+            L = TETHER[kind]
+            dim = 2 if kind.startswith("quad2d") else 3
+            ls = slice(5, 7) if dim == 2 else slice(10, 13)
+            d = np.linalg.norm(S[:, ls] - S[:, 0:dim], axis=1)
+            keep = np.abs(d - L) > 1e-3
+            S, A = S[keep], A[keep]
+        env = rh.RefEnv(kind)
+        env.env.g = np.array(GRAVITY[kind], dtype=np.float64)
+        S2, R, D, C = [], [], [], []
+        for s_, a_ in zip(S, A):
+            env.set_state(s_, sbd=None)
+            C.append(env.control())
+            env.set_state(s_, sbd=None)
+            o, r, d = env.step(a_)
+            S2.append(o)
+            R.append(r)
+            D.append(d)
+        out[kind + "_g"] = np.array(GRAVITY[kind], dtype=np.float64)
+        out[kind + "_s"], out[kind + "_a"] = S, A
+        out[kind + "_s2"], out[kind + "_r"], out[kind + "_d"] = np.array(S2), np.array(R), np.array(D, dtype=bool)
+        out[kind + "_ctrl"] = np.array(C)
+    path = os.path.join(HERE, "gravity.npz")
+    np.savez_compressed(path, **out)
+    print("gravity", {k: v.shape for k, v in out.items() if k.endswith("_s")}, os.path.getsize(path), "bytes")
+
+
 def main():
     assert rh.available(), "the reference tree is required to regenerate golden vectors"
     make_reinmav()
+    make_gravity()
     errs = rh.selfcheck_quaternion()
     assert max(errs) < 1e-14, errs
     for kind in rh.KINDS:

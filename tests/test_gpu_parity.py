@@ -97,6 +97,23 @@ def test_tilted_gravity_matches_the_oracle(G, kind):
     """The reference's self.g is a public VECTOR read by every step() (quadrotor3d.py:47,96-99; quadrotor2d.py:46,88) and by the
     3-D control() (:162); the 2-D control() keeps its literal (0, 9.8) (quadrotor2d.py:130).  rmav_params.g_vec carries it:
     single step, control(), and the fused controller-driven rollout against the oracle run with the same vector."""
+    # first against the REFERENCE's own outputs with a tilted vector assigned to its env object (tests/golden/gravity.npz)
+    gr = np.load(os.path.join(ROOT, "tests", "golden", "gravity.npz"))
+    env = G.BatchedQuadrotor(kind, len(gr[kind + "_s"]), auto_reset=False, track_episodes=False)
+    p = env.params
+    for i, v in enumerate(gr[kind + "_g"]):
+        p.g_vec[i] = float(v)
+    env.params = p
+    env.set_state(gr[kind + "_s"].astype(np.float32))
+    assert scaled_err(env.control(), gr[kind + "_ctrl"]).max() <= CTRL_TOL
+    obs, rew, done = env.step(gr[kind + "_a"].astype(np.float32))
+    assert scaled_err(obs, gr[kind + "_s2"]).max() <= TOL
+    okd = near_threshold(kind, gr[kind + "_s2"])
+    assert np.array_equal(done | okd, gr[kind + "_d"] | okd)
+    same = done == gr[kind + "_d"]
+    assert scaled_err(rew[same], gr[kind + "_r"][same]).max() <= TOL
+    env.close()
+    # then a big batch and the fused rollout against the oracle
     n = 20000 + 11
     s, a = random_cases(kind, n, seed=77)
     dim = 2 if kind.startswith("quad2d") else 3

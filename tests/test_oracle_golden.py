@@ -39,6 +39,30 @@ def test_control_matches_reference_vectors(kind, golden, built):
 
 
 @pytest.mark.parametrize("kind", KINDS)
+def test_tilted_gravity_matches_reference_vectors(kind, built):
+    """self.g is a public vector the reference reads on every call (quadrotor3d.py:47,96-99,162; quadrotor2d.py:46,88): the
+    oracle's g_vec against the reference's own step() / control() run with a TILTED vector assigned to the env object
+    (tests/golden/gravity.npz, make_golden.py::make_gravity).  The 2-D control() ignores it (its literal (0, 9.8),
+    quadrotor2d.py:130) - the fixture holds what the reference did."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gravity.npz"))
+    p = O.default_params(kind)
+    gv = g[kind + "_g"]
+    for i, v in enumerate(gv):
+        p.g_vec[i] = float(v)
+    s2, r, d, _ = O.batch_step(kind, g[kind + "_s"], g[kind + "_a"], params=p)
+    assert scaled_err(s2, g[kind + "_s2"]).max() < FP64_TOL
+    assert scaled_err(r, g[kind + "_r"]).max() < FP64_TOL and np.array_equal(d, g[kind + "_d"])
+    assert scaled_err(O.batch_control(kind, g[kind + "_s"], params=p), g[kind + "_ctrl"]).max() < FP64_TOL
+    # ... and the default vector gives something else for step() (and, for the 3-D kinds, for control())
+    s2d, *_ = O.batch_step(kind, g[kind + "_s"], g[kind + "_a"])
+    assert scaled_err(s2d, g[kind + "_s2"]).max() > 1e-5
+    cd = scaled_err(O.batch_control(kind, g[kind + "_s"]), g[kind + "_ctrl"]).max()
+    assert (cd > 1e-3) if kind.startswith("quad3d") else (cd < FP64_TOL)
+
+
+@pytest.mark.parametrize("kind", KINDS)
 def test_lifetime_terminal_reward_once(kind, golden, built):
     """Q1: reset() never clears steps_beyond_done, so the terminal reward is 1.0 once per env lifetime."""
     g = golden[kind]
