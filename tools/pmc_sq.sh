@@ -24,7 +24,7 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_rollout" in r["Kernel_Name"]:
+        if "k_rollout" in r["Kernel_Name"] or "k_step" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(acc):
     v = acc[k][len(acc[k]) // 4:]
